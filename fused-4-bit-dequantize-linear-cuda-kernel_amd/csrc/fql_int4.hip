@@ -1,0 +1,272 @@
+// libfql_int4.so -- C ABI (include/fql_int4.h) over the gfx950 kernels.
+//
+// Host-side dispatch only: argument validation, kernel selection, launches on the caller's
+// stream.  No allocation, no synchronisation, no state.
+#include "../../include/fql_int4.h"
+#include "fql_common.h"
+#include "fql_act_quant.h"
+#include "fql_gemm_i8.h"
+#include "fql_gemv.h"
+#include "fql_generic.h"
+
+namespace {
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline size_t round16(size_t v) { return (v + 15) & ~(size_t)15; }
+inline int padded_k(int K) { return (K + FQL_KPAD - 1) / FQL_KPAD * FQL_KPAD; }
+
+inline int limbs_of(int precision)
+{
+    if (precision == FQL_PRECISION_DEFAULT) return 3;
+    if (precision == FQL_PRECISION_FAST || precision == FQL_PRECISION_EXACT) return precision;
+    return -1;
+}
+
+struct Workspace {
+    int8_t *limbs;
+    float *delta;
+    int32_t *rowsum;
+    size_t bytes;
+};
+
+inline Workspace carve(void *base, int L, int T, int Kp)
+{
+    Workspace w;
+    const size_t lb = round16((size_t)L * T * Kp);
+    const size_t db = round16((size_t)T * sizeof(float));
+    const size_t rb = round16((size_t)L * T * sizeof(int32_t));
+    char *p = static_cast<char *>(base);
+    w.limbs = reinterpret_cast<int8_t *>(p);
+    w.delta = reinterpret_cast<float *>(p + lb);
+    w.rowsum = reinterpret_cast<int32_t *>(p + lb + db);
+    w.bytes = lb + db + rb;
+    return w;
+}
+
+// MFMA tile configuration (see fql_gemm_i8.h): 8 waves as 4(M) x 2(N), 32x64 outputs per wave
+// per limb -> 128 x 128 tile, 2 workgroups per CU.
+constexpr int CFG_WM = 4, CFG_WN = 2, CFG_MF = 1, CFG_NF = 2;
+constexpr int CFG_BM = 32 * CFG_MF * CFG_WM, CFG_BN = 32 * CFG_NF * CFG_WN;
+
+// The MFMA path addresses its operands through 32-bit buffer offsets.
+inline bool mfma_addressable(int L, int T, int K, int N)
+{
+    const size_t a = (size_t)L * ((size_t)T + CFG_BM) * (size_t)padded_k(K);
+    const size_t b = ((size_t)N + CFG_BN) * (size_t)(K >> 1);
+    return a < ((size_t)1 << 31) && b < ((size_t)1 << 31);
+}
+
+inline bool mfma_eligible(int L, int T, int K, int N, const uint8_t *packed)
+{
+    return (K % 32 == 0) && aligned16(packed) && mfma_addressable(L, T, K, N);
+}
+
+template <int L>
+int launch_act_quant(const float *x, const Workspace &w, int T, int K, int Kp, float *out, int N,
+                     const int32_t *tpe, const int32_t *offs, int E, hipStream_t st)
+{
+    hipLaunchKernelGGL((act_quant_kernel<L>), dim3(T), dim3(256), 0, st, x, w.limbs, w.delta, w.rowsum, T,
+                       K, Kp, out, N, tpe, offs, E);
+    return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
+}
+
+template <int L>
+int launch_gemm(const Workspace &w, const uint8_t *packed, const float *scales, const float *zps,
+                float *out, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int N,
+                hipStream_t st)
+{
+    const int n_tiles = (N + CFG_BN - 1) / CFG_BN;
+    const int m_slots = (tpe == nullptr) ? (T + CFG_BM - 1) / CFG_BM : T / CFG_BM + E;
+    const long long blocks = (long long)n_tiles * m_slots;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return FQL_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL((gemm_i8_kernel<L, CFG_WM, CFG_WN, CFG_MF, CFG_NF>), dim3((unsigned)blocks),
+                       dim3(64 * CFG_WM * CFG_WN), 0, st, w.limbs, w.delta, w.rowsum, packed, scales, zps, out,
+                       tpe, offs, E, T, K, Kp, N, n_tiles, m_slots);
+    return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
+}
+
+int run_mfma(int L, const float *x, const uint8_t *packed, const float *scales, const float *zps, float *out,
+             const int32_t *tpe, const int32_t *offs, int E, int T, int K, int N, void *workspace,
+             size_t workspace_bytes, hipStream_t st)
+{
+    const int Kp = padded_k(K);
+    if (workspace == nullptr || !aligned16(workspace)) return FQL_ERR_WORKSPACE;
+    const Workspace w = carve(workspace, L, T, Kp);
+    if (workspace_bytes < w.bytes) return FQL_ERR_WORKSPACE;
+    float *zero_out = (tpe != nullptr) ? out : nullptr;
+    int rc;
+    if (L == 2) {
+        rc = launch_act_quant<2>(x, w, T, K, Kp, zero_out, N, tpe, offs, E, st);
+        if (rc != FQL_OK) return rc;
+        return launch_gemm<2>(w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, N, st);
+    }
+    rc = launch_act_quant<3>(x, w, T, K, Kp, zero_out, N, tpe, offs, E, st);
+    if (rc != FQL_OK) return rc;
+    return launch_gemm<3>(w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, N, st);
+}
+
+int run_generic(const float *x, const uint8_t *packed, const float *scales, const float *zps, float *out,
+                const int32_t *tpe, const int32_t *offs, int E, int T, int K, int N, hipStream_t st)
+{
+    if (tpe != nullptr) {
+        hipLaunchKernelGGL(zero_uncovered_rows_kernel, dim3(T), dim3(256), 0, st, out, tpe, offs, E, T, N);
+        if (hipGetLastError() != hipSuccess) return FQL_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL((fused_rows_kernel<4>), dim3((N + 3) / 4, E), dim3(256), 0, st, x, packed, scales, zps,
+                       out, tpe, offs, T, K, N);
+    return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
+}
+
+size_t gemv_lds_bytes(int B, int K) { return ((size_t)B * (K >> 5) * GEMV_SEG + (size_t)B * 4) * sizeof(float); }
+
+template <int B>
+int launch_gemv(const float *x, const uint8_t *packed, const float *scales, const float *zps, float *out,
+                int K, int N, hipStream_t st)
+{
+    const int groups = (N + GEMV_ROWS - 1) / GEMV_ROWS;
+    int blocks = (groups + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    const size_t lds = gemv_lds_bytes(B, K);
+    if (lds > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemv_kernel<B>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return FQL_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL((gemv_kernel<B>), dim3(blocks), dim3(256), lds, st, x, packed, scales, zps, out, K, N);
+    return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fql_version(void) { return FQL_VERSION; }
+
+const char *fql_error_string(int code)
+{
+    switch (code) {
+    case FQL_OK: return "ok";
+    case FQL_ERR_NULL_POINTER: return "a required pointer is NULL";
+    case FQL_ERR_BAD_SHAPE: return "bad shape: dimensions must be positive and fit the addressable range";
+    case FQL_ERR_ODD_K: return "input_dim (K) must be even: two 4-bit weights per packed byte";
+    case FQL_ERR_WORKSPACE: return "workspace is NULL, not 16-byte aligned, or smaller than *_workspace_bytes()";
+    case FQL_ERR_LAUNCH: return "kernel launch failed (hipGetLastError)";
+    case FQL_ERR_BAD_PRECISION: return "precision must be FQL_PRECISION_DEFAULT, _FAST (2) or _EXACT (3)";
+    case FQL_ERR_ALIGNMENT: return "tensor base pointer not aligned as documented";
+    default: return "unknown error code";
+    }
+}
+
+int fql_act_padded_k(int K) { return K > 0 ? padded_k(K) : 0; }
+
+size_t fql_linear_workspace_bytes(int B, int K, int N, int precision)
+{
+    (void)N;
+    const int L = limbs_of(precision);
+    if (L < 0 || B <= 4 || K <= 0 || (K % 32) != 0) return 0;
+    Workspace w = carve(nullptr, L, B, padded_k(K));
+    return w.bytes;
+}
+
+size_t fql_moe_workspace_bytes(int E, int T, int K, int N, int precision)
+{
+    (void)E; (void)N;
+    const int L = limbs_of(precision);
+    if (L < 0 || T <= 0 || K <= 0 || (K % 32) != 0) return 0;
+    Workspace w = carve(nullptr, L, T, padded_k(K));
+    return w.bytes;
+}
+
+int fql_linear_fwd_f32(const float *x, const uint8_t *packed, const float *scales, const float *zps,
+                       float *out, int B, int K, int N, int precision, void *workspace,
+                       size_t workspace_bytes, void *stream)
+{
+    const int L = limbs_of(precision);
+    if (L < 0) return FQL_ERR_BAD_PRECISION;
+    if (B < 0 || K < 0 || N < 0) return FQL_ERR_BAD_SHAPE;
+    if (K & 1) return FQL_ERR_ODD_K;
+    if (B == 0 || N == 0) return FQL_OK;
+    if (!x || !packed || !scales || !zps || !out) return FQL_ERR_NULL_POINTER;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (K == 0) {                                     // empty contraction: out = 0
+        return hipMemsetAsync(out, 0, (size_t)B * N * sizeof(float), st) == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
+    }
+    if (B <= 4) {
+        if ((K % 32 == 0) && aligned16(packed) && aligned16(x) && gemv_lds_bytes(B, K) <= 150 * 1024) {
+            switch (B) {
+            case 1: return launch_gemv<1>(x, packed, scales, zps, out, K, N, st);
+            case 2: return launch_gemv<2>(x, packed, scales, zps, out, K, N, st);
+            case 3: return launch_gemv<3>(x, packed, scales, zps, out, K, N, st);
+            default: return launch_gemv<4>(x, packed, scales, zps, out, K, N, st);
+            }
+        }
+        return run_generic(x, packed, scales, zps, out, nullptr, nullptr, 1, B, K, N, st);
+    }
+    if (mfma_eligible(L, B, K, N, packed))
+        return run_mfma(L, x, packed, scales, zps, out, nullptr, nullptr, 1, B, K, N, workspace, workspace_bytes, st);
+    return run_generic(x, packed, scales, zps, out, nullptr, nullptr, 1, B, K, N, st);
+}
+
+int fql_moe_fwd_f32(const uint8_t *packed, const float *scales, const float *zps, const float *inputs,
+                    const int32_t *tokens_per_expert, const int32_t *input_offsets, float *out, int E, int T,
+                    int K, int N, int precision, void *workspace, size_t workspace_bytes, void *stream)
+{
+    const int L = limbs_of(precision);
+    if (L < 0) return FQL_ERR_BAD_PRECISION;
+    if (E < 0 || T < 0 || K < 0 || N < 0) return FQL_ERR_BAD_SHAPE;
+    if (K & 1) return FQL_ERR_ODD_K;
+    if (T == 0 || N == 0) return FQL_OK;
+    if (!out) return FQL_ERR_NULL_POINTER;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (E == 0 || K == 0) {                           // nothing contributes: all rows zero
+        return hipMemsetAsync(out, 0, (size_t)T * N * sizeof(float), st) == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
+    }
+    if (!packed || !scales || !zps || !inputs || !tokens_per_expert || !input_offsets) return FQL_ERR_NULL_POINTER;
+    if (E > 65535) return FQL_ERR_BAD_SHAPE;
+    if (mfma_eligible(L, T, K, N, packed))
+        return run_mfma(L, inputs, packed, scales, zps, out, tokens_per_expert, input_offsets, E, T, K, N,
+                        workspace, workspace_bytes, st);
+    return run_generic(inputs, packed, scales, zps, out, tokens_per_expert, input_offsets, E, T, K, N, st);
+}
+
+int fql_unpack_u8(const uint8_t *packed, uint8_t *q, size_t nbytes, void *stream)
+{
+    if (nbytes == 0) return FQL_OK;
+    if (!packed || !q) return FQL_ERR_NULL_POINTER;
+    size_t blocks = (nbytes / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(unpack_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       packed, q, nbytes);
+    return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
+}
+
+int fql_dequantize_f32(const uint8_t *packed, const float *scales, const float *zps, float *w, int N, int K,
+                       void *stream)
+{
+    if (N < 0 || K < 0) return FQL_ERR_BAD_SHAPE;
+    if (K & 1) return FQL_ERR_ODD_K;
+    if (N == 0 || K == 0) return FQL_OK;
+    if (!packed || !scales || !zps || !w) return FQL_ERR_NULL_POINTER;
+    hipLaunchKernelGGL(dequantize_kernel, dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), packed,
+                       scales, zps, w, N, K);
+    return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
+}
+
+int fql_act_quant_f32(const float *x, int8_t *limbs, float *delta, int32_t *rowsum, int T, int K, int precision,
+                      void *stream)
+{
+    const int L = limbs_of(precision);
+    if (L < 0) return FQL_ERR_BAD_PRECISION;
+    if (T < 0 || K <= 0) return FQL_ERR_BAD_SHAPE;
+    if (T == 0) return FQL_OK;
+    if (!x || !limbs || !delta || !rowsum) return FQL_ERR_NULL_POINTER;
+    if ((reinterpret_cast<uintptr_t>(limbs) & 7) != 0) return FQL_ERR_ALIGNMENT;
+    Workspace w;
+    w.limbs = limbs; w.delta = delta; w.rowsum = rowsum; w.bytes = 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (L == 2) return launch_act_quant<2>(x, w, T, K, padded_k(K), nullptr, 0, nullptr, nullptr, 0, st);
+    return launch_act_quant<3>(x, w, T, K, padded_k(K), nullptr, 0, nullptr, nullptr, 0, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,50 @@
+"""``QuantizedLinear`` -- nn.Module with the reference's exact surface (python/module.py:33-138):
+constructor ``(in_features, out_features)``, buffers ``packed_weights [N, K//2] uint8``,
+``scales [N] float32``, ``zero_points [N] float32`` (state_dict keys and shapes unchanged),
+``from_linear``, ``forward`` for 1-D / 2-D float32 input, ``extra_repr``.
+
+GPU tensors run the fused HIP kernels of libfql_int4.so (GEMV for B <= 4, INT8-limb MFMA GEMM
+otherwise); if the extension is not built that raises -- there is no silent fallback.  CPU tensors
+take the un-fused dequantize-then-matmul, exactly as the reference's ``forward`` does.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .quantize import quantize_weights, reference_quantized_linear
+
+
+class QuantizedLinear(nn.Module):
+    def __init__(self, in_features: int, out_features: int, precision: str = "default"):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.precision = precision
+        self.register_buffer("packed_weights", torch.zeros(out_features, in_features // 2, dtype=torch.uint8))
+        self.register_buffer("scales", torch.zeros(out_features, dtype=torch.float32))
+        self.register_buffer("zero_points", torch.zeros(out_features, dtype=torch.float32))
+
+    @classmethod
+    def from_linear(cls, linear: nn.Linear, precision: str = "default") -> "QuantizedLinear":
+        """Quantise an ``nn.Linear`` (bias unsupported, python/module.py:84)."""
+        assert linear.bias is None, "Bias not supported yet"
+        module = cls(linear.in_features, linear.out_features, precision=precision)
+        packed, scales, zero_points = quantize_weights(linear.weight.data)
+        module.packed_weights = packed
+        module.scales = scales
+        module.zero_points = zero_points
+        return module
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.is_cuda:
+            return self._forward_cuda(x)
+        return reference_quantized_linear(x, self.packed_weights, self.scales, self.zero_points)
+
+    def _forward_cuda(self, x: torch.Tensor) -> torch.Tensor:
+        from . import ops
+        return ops.linear_forward(x, self.packed_weights, self.scales, self.zero_points,
+                                  precision=self.precision)
+
+    def extra_repr(self) -> str:
+        return f"in_features={self.in_features}, out_features={self.out_features}, bits=4"

@@ -1,0 +1,176 @@
+"""MoE modules over the grouped INT4 GEMM.
+
+``MoEINT4`` / ``quantize_weights_moe``  -- surface of the reference's python/moe_int4_module.py:19-146
+    (stacked ``[E, N, K/2]`` buffers, per-TENSOR scale / zero-point broadcast to ``[E, N]``,
+    ``forward(inputs, expert_ids, tokens_per_expert, input_offsets)`` over rows pre-grouped by expert).
+``QuantizedMoEExpert`` / ``QuantizedMoE`` -- surface of benchmark/moe_grouped_gemm/moe_int4_module.py:21-130
+    (per-expert per-ROW quantisation, ``forward(List[Tensor]) -> List[Tensor]``).
+
+Both run ONE fused launch sequence for all experts on the GPU (device-side offsets, no per-expert
+launches or host syncs).  The reference's ``moe_int4_cuda`` kernel is defective; the
+semantics implemented are the ones its wrapper documents and ``QuantizedMoE.forward`` computes.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from .quantize import quantize_weights, dequantize_weights, pack_nibbles
+
+try:  # mirrors the reference's module-level availability flag (python/moe_int4_module.py:10-16)
+    from . import _native
+    _native.lib()
+    CUDA_AVAILABLE = True
+except Exception:  # library not built: MoEINT4.forward raises, as the reference does
+    CUDA_AVAILABLE = False
+
+
+def quantize_weights_moe(weights_list):
+    """List of ``[N, K]`` (fp16/fp32) -> stacked ``(packed [E,N,K/2], scales [E,N], zero_points [E,N])``.
+
+    Per expert, over the WHOLE tensor: ``scale = (max - min) / 15``, ``zp = clamp(round(-min/scale), 0, 15)``,
+    ``q = clamp(round(w/scale + zp), 0, 15)`` (python/moe_int4_module.py:45-59).  As in the reference
+    there is no guard for a constant tensor.
+    """
+    E = len(weights_list)
+    N, K = weights_list[0].shape
+    device = weights_list[0].device
+    packed = torch.zeros(E, N, K // 2, dtype=torch.uint8, device=device)
+    scales = torch.zeros(E, N, dtype=torch.float32, device=device)
+    zero_points = torch.zeros(E, N, dtype=torch.float32, device=device)
+    for e, w in enumerate(weights_list):
+        w32 = w.float()
+        lo, hi = torch.aminmax(w32)
+        scale = ((hi - lo) / 15.0).item()
+        zp = float(max(0, min(15, round((-lo / scale).item()))))
+        scales[e] = scale
+        zero_points[e] = zp
+        q = torch.round(w32 / scale + zp).clamp(0, 15).to(torch.uint8)
+        packed[e] = pack_nibbles(q)                 # one vectorised pack instead of a K/2-step loop
+    return packed, scales, zero_points
+
+
+class MoEINT4(nn.Module):
+    def __init__(self, num_experts, hidden_dim, ffn_dim, precision: str = "default"):
+        super().__init__()
+        self.num_experts = num_experts
+        self.hidden_dim = hidden_dim
+        self.ffn_dim = ffn_dim
+        self.packed_dim = hidden_dim // 2
+        self.precision = precision
+        self.register_buffer("packed_weights",
+                             torch.zeros(num_experts, ffn_dim, self.packed_dim, dtype=torch.uint8))
+        self.register_buffer("scales", torch.zeros(num_experts, ffn_dim, dtype=torch.float32))
+        self.register_buffer("zero_points", torch.zeros(num_experts, ffn_dim, dtype=torch.float32))
+
+    @classmethod
+    def from_weights(cls, weights_list, precision: str = "default"):
+        module = cls(len(weights_list), weights_list[0].shape[1], weights_list[0].shape[0], precision=precision)
+        packed, scales, zero_points = quantize_weights_moe(weights_list)
+        module.packed_weights = packed
+        module.scales = scales
+        module.zero_points = zero_points
+        return module
+
+    def forward(self, inputs, expert_ids, tokens_per_expert, input_offsets):
+        """inputs ``[T, K]`` float32 with rows grouped by expert -> ``[T, N]`` float32."""
+        if not CUDA_AVAILABLE:
+            raise RuntimeError("CUDA kernel not available")
+        from . import ops
+        return ops.moe_forward(self.packed_weights, self.scales, self.zero_points, inputs, expert_ids,
+                               tokens_per_expert, input_offsets, precision=self.precision)
+
+
+class QuantizedMoEExpert(nn.Module):
+    def __init__(self, in_features: int, out_features: int, precision: str = "default"):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.precision = precision
+        self.register_buffer("packed_weights", torch.zeros(out_features, in_features // 2, dtype=torch.uint8))
+        self.register_buffer("scales", torch.zeros(out_features, dtype=torch.float32))
+        self.register_buffer("zero_points", torch.zeros(out_features, dtype=torch.float32))
+
+    @classmethod
+    def from_fp16(cls, weight: torch.Tensor, precision: str = "default") -> "QuantizedMoEExpert":
+        assert weight.shape[1] % 2 == 0, "in_features must be even for INT4 packing"
+        expert = cls(weight.shape[1], weight.shape[0], precision=precision)
+        packed, scales, zero_points = quantize_weights(weight.float())
+        expert.packed_weights = packed
+        expert.scales = scales
+        expert.zero_points = zero_points
+        return expert
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.shape[0] == 0:      # reference quirk: always float16 (moe_int4_module.py:65-68)
+            return torch.empty(0, self.out_features, device=x.device, dtype=torch.float16)
+        if x.is_cuda:
+            from . import ops
+            y = ops.linear_forward(x.float().contiguous(), self.packed_weights, self.scales, self.zero_points,
+                                   precision=self.precision)
+            return y.to(x.dtype)
+        w = dequantize_weights(self.packed_weights, self.scales, self.zero_points)
+        return x @ w.T.to(x.dtype)
+
+    @property
+    def weight_memory_bytes(self) -> int:
+        return self.packed_weights.numel() + 4 * self.scales.numel() + 4 * self.zero_points.numel()
+
+
+class QuantizedMoE(nn.Module):
+    def __init__(self, num_experts: int, hidden_dim: int, ffn_dim: int, precision: str = "default"):
+        super().__init__()
+        self.num_experts = num_experts
+        self.hidden_dim = hidden_dim
+        self.ffn_dim = ffn_dim
+        self.precision = precision
+        self.experts = nn.ModuleList([QuantizedMoEExpert(hidden_dim, ffn_dim, precision)
+                                      for _ in range(num_experts)])
+        self._stacked = None        # lazily built [E,N,K/2] view of the experts' buffers for the grouped launch
+
+    @classmethod
+    def from_fp16_weights(cls, weights: List[torch.Tensor], precision: str = "default") -> "QuantizedMoE":
+        assert len(weights) > 0
+        moe = cls(len(weights), weights[0].shape[1], weights[0].shape[0], precision=precision)
+        for i, w in enumerate(weights):
+            moe.experts[i] = QuantizedMoEExpert.from_fp16(w, precision=precision)
+        return moe
+
+    def _stack(self, device):
+        key = tuple((e.packed_weights.data_ptr(), e.packed_weights._version) for e in self.experts)
+        if self._stacked is None or self._stacked[0] != key or self._stacked[1].device != device:
+            packed = torch.stack([e.packed_weights for e in self.experts]).to(device)
+            scales = torch.stack([e.scales for e in self.experts]).to(device)
+            zps = torch.stack([e.zero_points for e in self.experts]).to(device)
+            self._stacked = (key, packed, scales, zps)
+        return self._stacked[1:]
+
+    def forward(self, expert_inputs: List[torch.Tensor]) -> List[torch.Tensor]:
+        """One tensor ``[m_e, K]`` per expert in, one ``[m_e, N]`` per expert out (in x's dtype;
+        empty inputs give an empty float16 tensor, as the reference does)."""
+        if len(expert_inputs) == 0 or not expert_inputs[0].is_cuda:
+            return [expert(x) for expert, x in zip(self.experts, expert_inputs)]
+        from . import ops
+        dev = expert_inputs[0].device
+        counts = [int(x.shape[0]) for x in expert_inputs]
+        packed, scales, zps = self._stack(dev)
+        grouped = torch.cat([x.float() for x in expert_inputs], dim=0).contiguous()
+        tpe = torch.tensor(counts, dtype=torch.int32)
+        offs = torch.cumsum(tpe, 0, dtype=torch.int32) - tpe
+        out = ops.moe_forward(packed, scales, zps, grouped, None, tpe.to(dev, non_blocking=True),
+                              offs.to(dev, non_blocking=True), precision=self.precision) \
+            if grouped.shape[0] else grouped.new_zeros((0, self.ffn_dim))
+        outs, o = [], 0
+        for x, c in zip(expert_inputs, counts):
+            if c == 0:
+                outs.append(torch.empty(0, self.ffn_dim, device=x.device, dtype=torch.float16))
+            else:
+                outs.append(out[o:o + c].to(x.dtype))
+            o += c
+        return outs
+
+    @property
+    def total_memory_bytes(self) -> int:
+        return sum(e.weight_memory_bytes for e in self.experts)

@@ -1,0 +1,185 @@
+"""Operator boundary: tensor checks + raw-pointer calls into libfql_int4.so.
+
+``linear_forward`` mirrors ``fused_quant_linear_cuda.forward`` (reference
+csrc/quantized_linear.cpp:22-28 and the checks of csrc/quantized_linear_kernel.cu:293-378);
+``moe_forward`` mirrors ``moe_int4_cuda.forward`` (reference csrc/moe_int4_kernel.cu:93-141).
+Outputs are allocated here with torch (``torch.empty``), launches go to torch's current
+stream, nothing synchronises.  GPU tensors only -- a CPU tensor raises, exactly like the
+reference's TORCH_CHECK(input.is_cuda()).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _native
+
+_PRECISIONS = {"default": _native.PRECISION_DEFAULT, "exact": _native.PRECISION_EXACT,
+               "fast": _native.PRECISION_FAST, 0: 0, 2: 2, 3: 3}
+
+
+def _precision(p):
+    try:
+        return _PRECISIONS[p]
+    except KeyError:
+        raise ValueError(f"precision must be 'default', 'exact' or 'fast', got {p!r}") from None
+
+
+def _stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _workspace(nbytes, device):
+    if nbytes == 0:
+        return None, 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return ws, ws.data_ptr()
+
+
+def linear_forward(input, packed_weights, scales, zero_points, precision="default"):
+    """Fused 4-bit dequantize + linear forward.  input [K] or [B,K] float32 -> [N] or [B,N]."""
+    squeeze = False
+    if input.dim() == 1:                                   # :302-306
+        input = input.unsqueeze(0)
+        squeeze = True
+    # device / layout / dtype checks, same order and wording as :311-335
+    if not input.is_cuda:
+        raise RuntimeError("input must be a CUDA tensor")
+    if not packed_weights.is_cuda:
+        raise RuntimeError("packed_weights must be a CUDA tensor")
+    if not scales.is_cuda:
+        raise RuntimeError("scales must be a CUDA tensor")
+    if not zero_points.is_cuda:
+        raise RuntimeError("zero_points must be a CUDA tensor")
+    if not input.is_contiguous():
+        raise RuntimeError("input must be contiguous")
+    if not packed_weights.is_contiguous():
+        raise RuntimeError("packed_weights must be contiguous")
+    if input.dtype != torch.float32:
+        raise RuntimeError("input must be float32")
+    if packed_weights.dtype != torch.uint8:
+        raise RuntimeError("packed_weights must be uint8")
+    if scales.dtype != torch.float32:
+        raise RuntimeError("scales must be float32")
+    if zero_points.dtype != torch.float32:
+        raise RuntimeError("zero_points must be float32")
+    if input.dim() != 2 or packed_weights.dim() != 2:
+        raise RuntimeError("input must be 1-D or 2-D and packed_weights 2-D")
+    B, K = input.shape
+    N, packed_dim = packed_weights.shape
+    if packed_dim != K // 2 or K % 2 != 0:
+        raise RuntimeError("packed_weights dim 1 must be input_dim / 2")
+    # not checked by the reference (silent UB there); checked here
+    if scales.numel() != N or zero_points.numel() != N:
+        raise RuntimeError("scales and zero_points must have output_dim elements")
+    dev = input.device
+    if packed_weights.device != dev or scales.device != dev or zero_points.device != dev:
+        raise RuntimeError("all tensors must be on the same device")
+    scales = scales.contiguous()
+    zero_points = zero_points.contiguous()
+
+    L = _native.lib()
+    prec = _precision(precision)
+    out = torch.empty((B, N), dtype=torch.float32, device=dev)     # :338
+    with torch.cuda.device(dev):
+        ws, ws_ptr = _workspace(L.fql_linear_workspace_bytes(B, K, N, prec), dev)
+        rc = L.fql_linear_fwd_f32(input.data_ptr(), packed_weights.data_ptr(), scales.data_ptr(),
+                                  zero_points.data_ptr(), out.data_ptr(), B, K, N, prec,
+                                  ws_ptr, 0 if ws is None else ws.numel(), _stream_ptr(dev))
+    _native.check(rc, "fql_linear_fwd_f32")
+    return out.squeeze(0) if squeeze else out                      # :373-375
+
+
+def moe_forward(packed_weights, scales, zero_points, inputs, expert_ids, tokens_per_expert,
+                input_offsets, precision="default"):
+    """Grouped per-expert INT4 GEMM over rows pre-grouped by expert.
+
+    packed_weights [E,N,K/2] u8, scales/zero_points [E,N] f32, inputs [T,K] f32,
+    tokens_per_expert / input_offsets [E] int32 on the device (consumed there, no .item()).
+    ``expert_ids`` is accepted and ignored, as in the reference (csrc/moe_int4_kernel.cu:98).
+    Returns [T,N] float32; rows covered by no expert are zero (reference: torch::zeros :109).
+    """
+    del expert_ids
+    for name, t in (("packed_weights", packed_weights), ("scales", scales), ("zero_points", zero_points),
+                    ("inputs", inputs), ("tokens_per_expert", tokens_per_expert),
+                    ("input_offsets", input_offsets)):
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} must be a CUDA tensor")
+    if packed_weights.dtype != torch.uint8 or packed_weights.dim() != 3:
+        raise RuntimeError("packed_weights must be uint8 [num_experts, ffn_dim, hidden_dim/2]")
+    if inputs.dtype != torch.float32 or inputs.dim() != 2:
+        raise RuntimeError("inputs must be float32 [total_tokens, hidden_dim]")
+    if scales.dtype != torch.float32 or zero_points.dtype != torch.float32:
+        raise RuntimeError("scales and zero_points must be float32")
+    E, N, packed_dim = packed_weights.shape
+    T, K = inputs.shape
+    if K % 2 != 0 or packed_dim != K // 2:
+        raise RuntimeError("packed_weights dim 2 must be hidden_dim / 2")
+    if tuple(scales.shape) != (E, N) or tuple(zero_points.shape) != (E, N):
+        raise RuntimeError("scales and zero_points must be [num_experts, ffn_dim]")
+    if tokens_per_expert.numel() != E or input_offsets.numel() != E:
+        raise RuntimeError("tokens_per_expert and input_offsets must have num_experts elements")
+    dev = inputs.device
+    tpe = tokens_per_expert.to(torch.int32).contiguous()
+    offs = input_offsets.to(torch.int32).contiguous()
+    packed_weights = packed_weights.contiguous()
+    inputs = inputs.contiguous()
+    scales = scales.contiguous()
+    zero_points = zero_points.contiguous()
+
+    L = _native.lib()
+    prec = _precision(precision)
+    out = torch.empty((T, N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws, ws_ptr = _workspace(L.fql_moe_workspace_bytes(E, T, K, N, prec), dev)
+        rc = L.fql_moe_fwd_f32(packed_weights.data_ptr(), scales.data_ptr(), zero_points.data_ptr(),
+                               inputs.data_ptr(), tpe.data_ptr(), offs.data_ptr(), out.data_ptr(),
+                               E, T, K, N, prec, ws_ptr, 0 if ws is None else ws.numel(), _stream_ptr(dev))
+    _native.check(rc, "fql_moe_fwd_f32")
+    return out
+
+
+def unpack_nibbles(packed):
+    """q[..., 2j] = packed[..., j] & 15; q[..., 2j+1] = packed[..., j] >> 4 on the device."""
+    if not packed.is_cuda or packed.dtype != torch.uint8:
+        raise RuntimeError("packed must be a CUDA uint8 tensor")
+    packed = packed.contiguous()
+    q = torch.empty(packed.shape[:-1] + (packed.shape[-1] * 2,), dtype=torch.uint8, device=packed.device)
+    with torch.cuda.device(packed.device):
+        rc = _native.lib().fql_unpack_u8(packed.data_ptr(), q.data_ptr(), packed.numel(),
+                                         _stream_ptr(packed.device))
+    _native.check(rc, "fql_unpack_u8")
+    return q
+
+
+def dequantize_forward(packed_weights, scales, zero_points):
+    """GPU dequantize_weights: [N,K/2] u8 -> [N,K] f32 (python/quantize.py:127-173)."""
+    if not packed_weights.is_cuda:
+        raise RuntimeError("packed_weights must be a CUDA tensor")
+    packed_weights = packed_weights.contiguous()
+    N, K2 = packed_weights.shape
+    w = torch.empty((N, 2 * K2), dtype=torch.float32, device=packed_weights.device)
+    with torch.cuda.device(packed_weights.device):
+        rc = _native.lib().fql_dequantize_f32(packed_weights.data_ptr(), scales.contiguous().data_ptr(),
+                                              zero_points.contiguous().data_ptr(), w.data_ptr(), N, 2 * K2,
+                                              _stream_ptr(packed_weights.device))
+    _native.check(rc, "fql_dequantize_f32")
+    return w
+
+
+def act_quant(x, precision="default"):
+    """Activation pre-pass of the MFMA path (introspection for tests)."""
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2:
+        raise RuntimeError("x must be a CUDA float32 [T,K] tensor")
+    x = x.contiguous()
+    T, K = x.shape
+    prec = _precision(precision)
+    nl = 3 if prec == 0 else prec
+    Kp = _native.lib().fql_act_padded_k(K)
+    limbs = torch.empty((nl, T, Kp), dtype=torch.int8, device=x.device)
+    delta = torch.empty((T,), dtype=torch.float32, device=x.device)
+    rowsum = torch.empty((nl, T), dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _native.lib().fql_act_quant_f32(x.data_ptr(), limbs.data_ptr(), delta.data_ptr(), rowsum.data_ptr(),
+                                             T, K, prec, _stream_ptr(x.device))
+    _native.check(rc, "fql_act_quant_f32")
+    return limbs, delta, rowsum

@@ -1,0 +1,136 @@
+/*
+ * fql_int4.h -- C ABI of libfql_int4.so: fused INT4 dequantize-linear and grouped (MoE)
+ * per-expert INT4 GEMM for AMD Instinct MI355X (gfx950 / CDNA4).
+ *
+ * This header is the drop-in boundary.  It replaces, entry point for entry point, the two
+ * pybind11/libtorch operators of the reference (paths relative to the reference repository):
+ *
+ *   fql_linear_fwd_f32   <- fused_quant_linear_cuda.forward(input, packed_weights, scales, zero_points)
+ *                           csrc/quantized_linear.cpp:22-28, csrc/quantized_linear.h:29-34,
+ *                           host wrapper csrc/quantized_linear_kernel.cu:293-378
+ *   fql_moe_fwd_f32      <- moe_int4_cuda.forward(packed_weights, scales, zero_points, inputs,
+ *                                                 expert_ids, tokens_per_expert, input_offsets)
+ *                           csrc/moe_int4_kernel.cu:93-141, csrc/moe_int4_kernel.h:7-15
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / pybind types.  All data pointers are DEVICE
+ *     pointers (hipMalloc'd or a framework's device tensor storage) unless stated otherwise.
+ *   - the library owns nothing and allocates nothing: outputs and the scratch workspace are
+ *     caller-allocated; `*_workspace_bytes` says how much scratch a call needs.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *     null stream), performs no host synchronisation, keeps no state between calls and is
+ *     re-entrant.  It is safe to capture into a hipGraph.
+ *   - return value: FQL_OK (0) or a negative FQL_ERR_* code; fql_error_string() describes it.
+ *     Nothing is launched when an error is returned.
+ *
+ * Weight format (identical to the reference; python/quantize.py:120-122, :172):
+ *   packed[n][j] = (q[n][2j+1] << 4) | q[n][2j]      uint8, row-major [N][K/2]
+ *   w[n][k]      = (q[n][k] - zero_points[n]) * scales[n]          per-ROW scale / zero-point
+ */
+#ifndef FQL_INT4_H
+#define FQL_INT4_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FQL_VERSION 100 /* 0.1.0 */
+
+#if defined(__GNUC__)
+#define FQL_API __attribute__((visibility("default")))
+#else
+#define FQL_API
+#endif
+
+/* error codes */
+#define FQL_OK 0
+#define FQL_ERR_NULL_POINTER (-1)   /* a required pointer is NULL                                  */
+#define FQL_ERR_BAD_SHAPE (-2)      /* negative / zero dimension or size overflow                  */
+#define FQL_ERR_ODD_K (-3)          /* K must be even (two weights per byte)                       */
+#define FQL_ERR_WORKSPACE (-4)      /* workspace NULL, misaligned (16 B) or smaller than required  */
+#define FQL_ERR_LAUNCH (-5)         /* hipGetLastError() reported a launch failure                 */
+#define FQL_ERR_BAD_PRECISION (-6)  /* precision not one of FQL_PRECISION_*                        */
+#define FQL_ERR_ALIGNMENT (-7)      /* a tensor base pointer is not aligned as documented          */
+
+/* Activation precision of the MFMA path.  Weights are always exact (4-bit integers).
+ * Activations are split per row into signed 8-bit limbs of a fixed-point value; the integer
+ * dot products are exact (i32 MFMA accumulation), so the only error is the one rounding of
+ * each activation to 2^-(8*limbs-1) of its row's maximum magnitude:
+ *   FQL_PRECISION_EXACT : 3 limbs, 23-bit fixed point -> float32-class results (default;
+ *                         meets the reference's own allclose(atol=1e-3) GPU tests)
+ *   FQL_PRECISION_FAST  : 2 limbs, 15-bit fixed point -> ~3e-5 relative (Frobenius) error,
+ *                         2/3 of the matrix-core work                                        */
+#define FQL_PRECISION_DEFAULT 0
+#define FQL_PRECISION_FAST 2
+#define FQL_PRECISION_EXACT 3
+
+FQL_API int fql_version(void);
+FQL_API const char *fql_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused INT4 dequantize-linear:  out[b][n] = sum_k x[b][k] * (q[n][k] - zp[n]) * scale[n]
+ *
+ *   x       [B][K] float32, contiguous          (reference: `input`, 1-D inputs are B = 1)
+ *   packed  [N][K/2] uint8, contiguous
+ *   scales  [N] float32,  zps [N] float32
+ *   out     [B][N] float32, contiguous, fully overwritten
+ *   workspace: fql_linear_workspace_bytes(B, K, N, precision) bytes, 16-byte aligned
+ *              (0 bytes are needed for B <= 4: pass NULL)
+ * Any even K is accepted; K % 32 == 0 with 16-byte aligned `packed` takes the fast paths.
+ * ------------------------------------------------------------------------------------- */
+FQL_API size_t fql_linear_workspace_bytes(int B, int K, int N, int precision);
+
+FQL_API int fql_linear_fwd_f32(const float *x, const uint8_t *packed, const float *scales,
+                       const float *zps, float *out, int B, int K, int N, int precision,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Grouped (MoE) INT4 GEMM over rows pre-grouped by expert:
+ *   for every expert e:  out[off_e : off_e+cnt_e] = inputs[off_e : off_e+cnt_e] @ dequant(W_e)^T
+ *   rows of `out` covered by no expert are set to zero (reference: torch::zeros, :109)
+ *
+ *   packed  [E][N][K/2] uint8;  scales, zps [E][N] float32
+ *   inputs  [T][K] float32;     out [T][N] float32, fully overwritten
+ *   tokens_per_expert [E] int32 (cnt_e), input_offsets [E] int32 (off_e): DEVICE arrays,
+ *     consumed on the device -- no host read-back, one launch sequence for all experts.
+ *     Ranges are clipped to [0, T]; they must not overlap.
+ *   (`expert_ids` of the reference signature is accepted by the Python shim and ignored,
+ *    exactly as the reference ignores it: csrc/moe_int4_kernel.cu:98.)
+ * ------------------------------------------------------------------------------------- */
+FQL_API size_t fql_moe_workspace_bytes(int E, int T, int K, int N, int precision);
+
+FQL_API int fql_moe_fwd_f32(const uint8_t *packed, const float *scales, const float *zps,
+                    const float *inputs, const int32_t *tokens_per_expert,
+                    const int32_t *input_offsets, float *out, int E, int T, int K, int N,
+                    int precision, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Format helpers on the device (same unpack code path as the GEMM kernels; bit-exact).
+ *   fql_unpack_u8     : q[i][2j] = packed[i][j] & 15, q[i][2j+1] = packed[i][j] >> 4
+ *                       (python/quantize.py:152-163)
+ *   fql_dequantize_f32: w[n][k] = (q[n][k] - zps[n]) * scales[n]   (python/quantize.py:172)
+ * ------------------------------------------------------------------------------------- */
+FQL_API int fql_unpack_u8(const uint8_t *packed, uint8_t *q, size_t nbytes, void *stream);
+
+FQL_API int fql_dequantize_f32(const uint8_t *packed, const float *scales, const float *zps, float *w,
+                       int N, int K, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Introspection for tests: the activation pre-pass of the MFMA path.
+ *   limbs  [precision][T][Kp] int8 (Kp = fql_act_padded_k(K)), k permuted inside every aligned
+ *          group of 8 as (0,2,4,6,1,3,5,7) to match the in-register nibble unpack order
+ *   delta  [T] float32 (power of two), rowsum [precision][T] int32
+ *   x[t][k] ~= delta[t] * sum_l 256^l * limb_l[t][k]
+ * ------------------------------------------------------------------------------------- */
+FQL_API int fql_act_padded_k(int K);
+
+FQL_API int fql_act_quant_f32(const float *x, int8_t *limbs, float *delta, int32_t *rowsum, int T, int K,
+                      int precision, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FQL_INT4_H */
