@@ -1,0 +1,328 @@
+#!/usr/bin/env python3
+"""Benchmark of the fused INT4 hot path on MI355X (contract: see the task statement / DESIGN.md).
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload moe|linear512|linear1]
+
+A *step* is one pass of the hot path over one batch of synthetic input, inputs resident in HBM:
+  moe       (default, BASELINE.json configs[2]) QuantizedMoE 8 experts 4096->11008, 512 tokens top-2
+            = 1024 routed rows pre-grouped by expert: activation pre-pass + grouped INT4 GEMM.
+  linear512 (configs[1]) QuantizedLinear 4096->11008, batch 512.
+  linear1   (configs[0] shape on the GPU) QuantizedLinear 4096->11008, batch 1 (GEMV kernel).
+With --gpus N > 1 (launched under torch.distributed.run, one rank per GPU) the MoE workload is
+expert-sharded: E/N experts and 512/N tokens per rank, RCCL all-to-all dispatch and combine
+(strong scaling: the total work is the 1-GPU workload).
+
+Rank 0 prints ONE JSON line.  `value` = algorithmic TFLOP/s of the whole job, 2*rows*K*N flops per
+step (each multiply-add counted once, however many INT8 limbs the kernel spends on it).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_I8_PEAK_TOPS = 5000.0      # dense INT8 MFMA = 2x the ~2.5 PF bf16 dense rate (microarch guide, Matrix cores)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="moe", choices=["moe", "linear512", "linear1"])
+    ap.add_argument("--precision", default="default", choices=["default", "exact", "fast"])
+    ap.add_argument("--routing", default="balanced", choices=["balanced", "skewed"])
+    ap.add_argument("--weight-sets", type=int, default=4,
+                    help="distinct weight copies rotated through so that consecutive steps cannot be served "
+                         "from the 256 MB Infinity Cache (4 x 180 MB); 1 = warm-cache numbers")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--experts", type=int, default=8)
+    ap.add_argument("--hidden", type=int, default=4096)
+    ap.add_argument("--ffn", type=int, default=11008)
+    ap.add_argument("--tokens", type=int, default=512)
+    ap.add_argument("--top-k", type=int, default=2)
+    return ap.parse_args()
+
+
+def quantize_on_device(w):
+    import fused_int4_amd as fq
+    return fq.quantize_weights(w)
+
+
+def make_weights(E, N, K, dev, seed):
+    """randn(N,K)*0.02 per expert (reference: benchmark/moe_grouped_gemm/moe_int4_module.py:151-154),
+    quantised per row with the package's quantize_weights."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    P, S, Z = [], [], []
+    for _ in range(E):
+        w = torch.randn(N, K, device=dev, generator=g) * 0.02
+        p, s, z = quantize_on_device(w)
+        P.append(p); S.append(s); Z.append(z)
+        del w
+    return torch.stack(P), torch.stack(S), torch.stack(Z)
+
+
+def cpu_baseline_moe(P, S, Z, x, tpe, offs, K, N, max_seconds=30.0):
+    """The oracle (CPU port of the reference's dequantize-then-matmul, applied per expert) timed on the
+    host cores, on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    Pn, Sn, Zn, xn = P.cpu().numpy(), S.cpu().numpy(), Z.cpu().numpy(), x.cpu().numpy()
+    tp, of = tpe.cpu().numpy(), offs.cpu().numpy()
+    E = Pn.shape[0]
+    O.reference_quantized_linear(xn[:8], Pn[0][:256], Sn[0][:256], Zn[0][:256])       # warm the BLAS threads
+    t0 = time.perf_counter()
+    rows_done, experts_done = 0, 0
+    for e in range(E):
+        c, o = int(tp[e]), int(of[e])
+        if c > 0:
+            O.reference_quantized_linear(xn[o:o + c], Pn[e], Sn[e], Zn[e])
+        rows_done += c
+        experts_done += 1
+        if time.perf_counter() - t0 > max_seconds:
+            break
+    dt = time.perf_counter() - t0
+    flops = 2.0 * rows_done * K * N
+    return {"value": flops / dt / 1e12, "unit": "TFLOP/s", "cores": threads, "kind": "port",
+            "sample": f"{experts_done} of {E} experts ({rows_done} routed rows), one pass, "
+                      f"dequantize_weights + F.linear per expert, {dt:.2f} s",
+            "seconds": dt}
+
+
+def cpu_baseline_linear(p, s, z, x, K, N):
+    from oracle import oracle as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    pn, sn, zn, xn = p.cpu().numpy(), s.cpu().numpy(), z.cpu().numpy(), x.cpu().numpy()
+    O.reference_quantized_linear(xn[:1], pn[:256], sn[:256], zn[:256])
+    reps, t0 = 0, time.perf_counter()
+    while reps < 3 or (time.perf_counter() - t0 < 10.0 and reps < 20):
+        O.reference_quantized_linear(xn, pn, sn, zn)
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": 2.0 * xn.shape[0] * K * N / dt / 1e12, "unit": "TFLOP/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} full passes of dequantize_weights + F.linear, batch {xn.shape[0]}, {dt*1e3:.1f} ms each",
+            "seconds": dt * reps}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import fused_int4_amd as fq
+    from fused_int4_amd import ops, routing as R
+    from fused_int4_amd.ep import ExpertParallelMoE
+
+    E, K, N = a.experts, a.hidden, a.ffn
+    prec = a.precision
+    limbs = 2 if prec == "fast" else 3
+    extra = {}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # ------------------------------------------------------------------ build the workload
+    if a.workload == "moe" and world == 1:
+        T = a.tokens * a.top_k
+        sets = [make_weights(E, N, K, dev, 42 + i) for i in range(max(1, a.weight_sets))]
+        route = (R.balanced_routing if a.routing == "balanced" else
+                 lambda t, e, k, device, seed: R.simulate_routing(t, e, k, "skewed", device, seed))(
+            a.tokens, E, a.top_k, device=dev, seed=42)
+        torch.manual_seed(42)
+        x_tok = torch.randn(a.tokens, K, device=dev)
+        x, tpe, offs, _ = R.dispatch_grouped(x_tok, route.expert_indices, E)
+        x = x.contiguous()
+        rows = T
+        step_i = [0]
+
+        def step():
+            P, S, Z = sets[step_i[0] % len(sets)]
+            step_i[0] += 1
+            return ops.moe_forward(P, S, Z, x, None, tpe, offs, precision=prec)
+
+        def phases(i):   # the same two kernels through the two-phase C entry points, for per-kernel timing
+            P, S, Z = sets[i % len(sets)]
+            return P, S, Z, tpe, offs
+        flops = 2.0 * rows * K * N
+        weight_bytes = E * N * (K // 2)
+        all_bytes = weight_bytes + 2 * E * N * 4 + rows * K * 4 + rows * N * 4
+        workload = f"QuantizedMoE {E} experts {K}->{N} top-{a.top_k}, batch {a.tokens} ({rows} routed rows, {a.routing})"
+        parallelism = "1 GPU"
+    elif a.workload == "moe":
+        assert E % world == 0 and a.tokens % world == 0
+        Pfull = None
+        # every rank builds only its own experts' weights (same seeds as the 1-GPU run would use per expert block)
+        EL = E // world
+        g = torch.Generator(device=dev).manual_seed(42)
+        sets = [make_weights(EL, N, K, dev, 42 + 1000 * rank + i) for i in range(max(1, a.weight_sets))]
+        t_local = a.tokens // world
+        route = R.balanced_routing(a.tokens, E, a.top_k, device=dev, seed=42)
+        idx = route.expert_indices[rank * t_local:(rank + 1) * t_local].contiguous()
+        wts = route.expert_weights[rank * t_local:(rank + 1) * t_local].contiguous()
+        torch.manual_seed(42 + rank)
+        x = torch.randn(t_local, K, device=dev)
+        eps = [ExpertParallelMoE(E, P, S, Z, precision=prec) for (P, S, Z) in sets]
+        step_i = [0]
+
+        def step():
+            ep = eps[step_i[0] % len(eps)]
+            step_i[0] += 1
+            return ep(x, idx, wts)
+        phases = None
+        rows = a.tokens * a.top_k
+        flops = 2.0 * rows * K * N
+        weight_bytes = E * N * (K // 2)
+        all_bytes = weight_bytes + 2 * E * N * 4 + rows * K * 4 + rows * N * 4
+        workload = (f"QuantizedMoE {E} experts sharded {EL}/GPU over {world} GPUs, {K}->{N} top-{a.top_k}, "
+                    f"batch {a.tokens}, RCCL all-to-all dispatch/combine")
+        parallelism = f"ep{world}"
+    else:
+        B = 512 if a.workload == "linear512" else 1
+        sets = [tuple(t[0] for t in make_weights(1, N, K, dev, 42 + i)) for i in range(max(1, a.weight_sets))]
+        torch.manual_seed(42)
+        x = torch.randn(B, K, device=dev)
+        rows = B
+        step_i = [0]
+
+        def step():
+            p, s, z = sets[step_i[0] % len(sets)]
+            step_i[0] += 1
+            return ops.linear_forward(x, p, s, z, precision=prec)
+
+        def phases(i):
+            p, s, z = sets[i % len(sets)]
+            return p, s, z, None, None
+        if B <= 4:
+            phases = None
+        flops = 2.0 * B * K * N
+        weight_bytes = N * (K // 2)
+        all_bytes = weight_bytes + 2 * N * 4 + B * K * 4 + B * N * 4
+        workload = f"QuantizedLinear {K}->{N}, batch {B}"
+        parallelism = "replicas only" if world > 1 else "1 GPU"
+
+    # ------------------------------------------------------------------ timed region (the contract)
+    for _ in range(a.warmup):
+        step()
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize(); barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_per_step = elapsed / a.steps * 1e3
+    total_flops = flops * (world if (a.workload != "moe" and world > 1) else 1)
+    value = total_flops / (ms_per_step * 1e-3) / 1e12
+
+    # ------------------------------------------------------------------ per-kernel durations (HIP events on the launch stream)
+    roofline = None
+    if phases is not None and world == 1:
+        n = a.steps
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)]
+        outs = torch.empty((rows, N), dtype=torch.float32, device=dev)
+        for i in range(n):
+            Pw, Sw, Zw, tp, of = phases(i)
+            ev[i][0].record()
+            lm, dl, rs = ops.act_quant(x, precision=prec, tokens_per_expert=tp, input_offsets=of)
+            ev[i][1].record()
+            ops.gemm_i8(lm, dl, rs, Pw, Sw, Zw, tp, of, precision=prec, out=outs)
+            ev[i][2].record()
+        torch.cuda.synchronize()
+        pre = sorted(e[0].elapsed_time(e[1]) for e in ev)
+        gem = sorted(e[1].elapsed_time(e[2]) for e in ev)
+        gemm_ms = sum(gem) / n
+        extra.update({"gemm_kernel_ms_avg": gemm_ms, "gemm_kernel_ms_median": gem[n // 2], "gemm_kernel_ms_min": gem[0],
+                      "act_quant_ms_avg": sum(pre) / n, "act_quant_ms_median": pre[n // 2]})
+        mfma_achieved = flops / (gemm_ms * 1e-3) / 1e12
+        hbm_achieved = weight_bytes / (gemm_ms * 1e-3) / 1e9
+        mfma_floor_ms = flops * limbs / (MFMA_I8_PEAK_TOPS * 1e12) * 1e3
+        hbm_floor_ms = weight_bytes / (HBM_PEAK_GBPS * 1e9) * 1e3
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", f"pmc_traffic_{a.workload}.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        if mfma_floor_ms >= hbm_floor_ms:
+            roofline = {"bound": "mfma", "kernel": "gemm_i8_kernel", "achieved": mfma_achieved, "peak": MFMA_I8_PEAK_TOPS,
+                        "unit": "TFLOP/s", "frac": mfma_achieved / MFMA_I8_PEAK_TOPS, "traffic": traffic,
+                        "note": f"algorithmic flops 2*rows*K*N counted once; the kernel issues {limbs} INT8 MFMA passes "
+                                f"(one per activation limb), so frac <= 1/{limbs} by construction"}
+        else:
+            roofline = {"bound": "hbm", "kernel": "gemm_i8_kernel", "achieved": hbm_achieved, "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBPS, "traffic": traffic}
+        extra["roofline_hbm_packed_weights"] = {"achieved": hbm_achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                                "frac": hbm_achieved / HBM_PEAK_GBPS, "bytes": weight_bytes}
+        extra["roofline_mfma_i8"] = {"achieved": mfma_achieved, "peak": MFMA_I8_PEAK_TOPS, "unit": "TFLOP/s",
+                                     "frac": mfma_achieved / MFMA_I8_PEAK_TOPS, "issued_frac": mfma_achieved * limbs / MFMA_I8_PEAK_TOPS}
+    elif world == 1:   # GEMV: one kernel per step; event-time the product call itself
+        n = a.steps
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for i in range(n):
+            ev[i][0].record(); step(); ev[i][1].record()
+        torch.cuda.synchronize()
+        ts = sorted(e[0].elapsed_time(e[1]) for e in ev)
+        k_ms = sum(ts) / n
+        ach = (weight_bytes + 2 * N * 4 + rows * K * 4) / (k_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "gemv_kernel", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBPS, "traffic": None}
+        extra.update({"gemv_kernel_ms_avg": k_ms, "gemv_kernel_ms_median": ts[n // 2], "gemv_kernel_ms_min": ts[0]})
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
+    cpu = None
+    if world == 1 and not a.no_cpu_baseline:
+        if a.workload == "moe":
+            P, S, Z = sets[0]
+            cpu = cpu_baseline_moe(P, S, Z, x, tpe, offs, K, N)
+        else:
+            p, s, z = sets[0]
+            cpu = cpu_baseline_linear(p, s, z, x, K, N)
+
+    if rank == 0:
+        line = {
+            "metric": "fused INT4 GEMM effective TFLOP/s (ms, HBM GB/s and roofline fractions alongside)",
+            "value": value, "unit": "TFLOP/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong" if a.workload == "moe" else "weak",
+            "vs_baseline": None, "dtype": "i8" if not (a.workload == "linear1") else "f32", "data": "synthetic",
+            "config": {"workload": workload, "precision": prec, "activation_limbs": limbs,
+                       "parallelism": parallelism,
+                       "cache": (f"cold: {len(sets)} weight sets rotated" if len(sets) > 1 else "warm: one weight set")},
+            "algorithmic_flops_per_step": flops, "packed_weight_bytes": weight_bytes, "all_bytes": all_bytes,
+            "hbm_GBps_packed_weights_e2e": weight_bytes / (ms_per_step * 1e-3) / 1e9,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        line.update(extra)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (loads libamdhip64 first)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libfql_int4.so")
+SO_PATH = os.environ.get("FQL_INT4_LIB") or os.path.join(CSRC, "libfql_int4.so")   # env override: experiments only
 
 PRECISION_DEFAULT = 0
 PRECISION_FAST = 2
@@ -34,7 +34,9 @@ _SYMBOLS = {
     "fql_unpack_u8": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "fql_dequantize_f32": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),
     "fql_act_padded_k": (ctypes.c_int, [ctypes.c_int]),
-    "fql_act_quant_f32": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "fql_act_limb_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
+    "fql_act_quant_f32": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "fql_gemm_i8_f32": (ctypes.c_int, [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
 }
 
 _lib = None

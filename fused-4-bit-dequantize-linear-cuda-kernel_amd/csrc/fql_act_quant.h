@@ -1,12 +1,21 @@
 // Activation pre-pass of the MFMA path: float32 rows -> signed 8-bit limbs of a per-row
-// fixed-point value, laid out for the GEMM's LDS-DMA fills.
+// fixed-point value, written in the layout the GEMM's matrix-core A operand wants.
 //
 //   x[t][k] ~= delta[t] * X[t][k],   X = sum_l 256^l * a_l,   a_l in [-128, 127]  (balanced digits)
 //   delta[t] = 2^e, the smallest power of two with rint(max_k |x[t][k]| / 2^e) <= LIM(L)
-//   limbs[l][t][k'] : k permuted inside every aligned group of 8 as (0,2,4,6,1,3,5,7), which is
-//                     the order the in-register nibble unpack (unpack8) produces for the weights;
-//                     columns K..Kp-1 are zero
-//   rowsum[l][t]    = sum_k a_l[t][k]      (folds the zero-point: sum_k (q-zp) a = sum q a - zp * rowsum)
+//   rowsum[l][t] = sum_k a_l[t][k]      (folds the zero-point: sum_k (q-zp) a = sum q a - zp * rowsum)
+//
+// Limb layout ("fragment native"):  limbs[l][kb][mb][ks][lane][16 B]
+//   kb  = k / 256                      weight-stage block (FQL_KB)
+//   mb  = p / 32, p = padded row       expert e's rows start at pbase_e = sum_{e'<e} roundup(cnt_e', 32)
+//   ks  = 0..7                         the 32-deep MFMA k-step inside the block
+//   lane = g*32 + (p & 31)             exactly the lane that supplies row p to v_mfma_i32_32x32x32_i8
+//   so one wave's A fragment for (l, kb, mb, ks) is 1 KiB contiguous: a single coalesced
+//   buffer_load_dwordx4, no LDS.  Which 16 k a lane holds follows the weight side: lane group g of
+//   step ks = 2v+b pairs with bytes [8b, 8b+8) of 16-byte chunk c = 2v+g of the weight row's 128-byte
+//   stage segment, i.e. k = 32c + 16b + [0,16) of the block; inside every aligned group of 8 the order
+//   is (0,2,4,6,1,3,5,7), the order the in-register nibble unpack (unpack8) produces.
+//   Columns K..Kp-1 are zero.
 //
 // HBM-bound: reads T*K*4 bytes (second pass hits L2), writes L*T*Kp bytes.  One 256-thread
 // workgroup per row.  For the MoE entry point the same launch also zero-fills the rows of `out`
@@ -32,10 +41,20 @@ __device__ __forceinline__ int act_exponent(float m)
     return e;
 }
 
+// byte offset of the 8-byte group holding k0..k0+7 (k0 % 8 == 0) of padded row p, limb l
+__device__ __forceinline__ size_t limb_offset(int l, int k0, int p, int KB, int MBT)
+{
+    const int kb = k0 >> 8, kin = k0 & 255;
+    const int c = kin >> 5, v = c >> 1, g = c & 1, b = (kin >> 4) & 1;
+    const int ks = 2 * v + b;
+    const size_t blk = ((size_t)l * KB + kb) * MBT + (p >> 5);
+    return ((blk * 8 + ks) * 64 + (g * 32 + (p & 31))) * 16 + (kin & 8);
+}
+
 template <int L>
 __global__ __launch_bounds__(256) void act_quant_kernel(
     const float *__restrict__ x, int8_t *__restrict__ limbs, float *__restrict__ delta,
-    int32_t *__restrict__ rowsum, int T, int K, int Kp,
+    int32_t *__restrict__ rowsum, int T, int K, int Kp, int MBT,
     float *__restrict__ out, int N, const int32_t *__restrict__ tpe,
     const int32_t *__restrict__ offs, int E)
 {
@@ -46,17 +65,24 @@ __global__ __launch_bounds__(256) void act_quant_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
 
-    if (out != nullptr) {                 // MoE: rows covered by no expert are zeroed, not computed
+    int p = t;                            // padded row of t in the limb workspace
+    if (tpe != nullptr) {                 // MoE: find the covering expert and its padded base
         bool covered = false;
+        int pbase = 0;
         for (int e = 0; e < E; ++e) {
-            long long lo = offs[e], hi = lo + (long long)tpe[e];
-            lo = lo < 0 ? 0 : lo;
-            hi = hi > T ? T : hi;
-            covered |= (t >= lo && t < hi);
+            int lo, cnt;
+            expert_range(tpe, offs, e, T, lo, cnt);
+            if (!covered && t >= lo && t < lo + cnt) {
+                covered = true;
+                p = pbase + (t - lo);
+            }
+            pbase += (cnt + FQL_MB - 1) / FQL_MB * FQL_MB;
         }
-        if (!covered) {
-            float *orow = out + (size_t)t * N;
-            for (int i = tid; i < N; i += 256) orow[i] = 0.0f;
+        if (!covered) {                   // rows covered by no expert are zeroed, not computed
+            if (out != nullptr) {
+                float *orow = out + (size_t)t * N;
+                for (int i = tid; i < N; i += 256) orow[i] = 0.0f;
+            }
             return;
         }
     }
@@ -95,6 +121,7 @@ __global__ __launch_bounds__(256) void act_quant_kernel(
 
     const int e = act_exponent<L>(m);
     const float inv = ldexpf(1.0f, -e);
+    const int KB = Kp / FQL_KB;
 
     // pass 2: quantise 8 consecutive k per thread, write one permuted 8-byte group per limb
     int sums[L];
@@ -102,8 +129,8 @@ __global__ __launch_bounds__(256) void act_quant_kernel(
     for (int l = 0; l < L; ++l) sums[l] = 0;
 
     const int G = Kp >> 3;
-    for (int g = tid; g < G; g += 256) {
-        const int k0 = g << 3;
+    for (int gi = tid; gi < G; gi += 256) {
+        const int k0 = gi << 3;
         float v[8];
         if (vec_ok && k0 + 8 <= K) {
             v4f a = *reinterpret_cast<const v4f *>(xr + k0);
@@ -131,10 +158,8 @@ __global__ __launch_bounds__(256) void act_quant_kernel(
             }
         }
 #pragma unroll
-        for (int l = 0; l < L; ++l) {
-            uint2 pk = make_uint2(w[l][0], w[l][1]);
-            *reinterpret_cast<uint2 *>(limbs + ((size_t)l * T + t) * Kp + k0) = pk;
-        }
+        for (int l = 0; l < L; ++l)
+            *reinterpret_cast<uint2 *>(limbs + limb_offset(l, k0, p, KB, MBT)) = make_uint2(w[l][0], w[l][1]);
     }
 #pragma unroll
     for (int l = 0; l < L; ++l) {

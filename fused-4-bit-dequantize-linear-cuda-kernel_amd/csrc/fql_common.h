@@ -8,10 +8,12 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 #define FQL_WAVE 64
-// K-depth of one LDS stage of the MFMA GEMM, in activation elements (= int8 bytes per limb row).
-#define FQL_BK 64
-// Activation limb rows are zero-padded to a multiple of this (>= FQL_BK, room for deeper stages).
-#define FQL_KPAD 128
+// K-depth of one weight stage of the MFMA GEMM: 256 k = 128 packed bytes = one full cache line per
+// weight row.  The activation limbs are written by the pre-pass in blocks of the same depth.
+#define FQL_KB 256
+// Rows of one MFMA row-block (v_mfma_i32_32x32x32_i8).  Every expert's rows start at a multiple of
+// this in the limb workspace, so a wave's A fragment is one contiguous 1 KiB.
+#define FQL_MB 32
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
 
@@ -50,4 +52,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk)
     const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
     const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
     return base + (bid >> 3);
+}
+
+// Expert row ranges live on the device (tokens_per_expert / input_offsets).  Clip to [0, T].
+__device__ __forceinline__ void expert_range(const int32_t *tpe, const int32_t *offs, int i, int T, int &lo, int &cnt)
+{
+    long long a = offs[i], b = a + (long long)tpe[i];
+    a = a < 0 ? 0 : a;
+    b = b > T ? T : b;
+    lo = (int)a;
+    cnt = b > a ? (int)(b - a) : 0;
 }

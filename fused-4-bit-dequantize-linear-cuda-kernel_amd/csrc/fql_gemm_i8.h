@@ -6,15 +6,19 @@
 // for every row t of expert e's range.  The inner integer dot products are exact (i32
 // accumulation), so results do not depend on tile shape, K order or which GPU ran the row.
 //
-// Data movement per workgroup (BM = 32*MF*WM rows, BN = 32*NF*WN output columns, BK = 64):
-//   * packed weights: HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), each byte once per
-//     workgroup; read back with one ds_read_b128 per 32x64 fragment; nibbles are unpacked in
-//     registers with 3 VALU ops per 8 weights (unpack8) straight into the MFMA B operand.
-//   * activation limbs: L2 -> LDS by LDS-DMA; ds_read_b128 per 32x32 A fragment.
-//   * LDS images are XOR-swizzled on the DMA *source* side (the LDS destination of an LDS-DMA is
-//     lane-linear) so that both fragment reads are bank-conflict-free.
-//   * double-buffered stages, one workgroup barrier per stage; loads of stage s+1 fly under the
-//     MFMAs of stage s.
+// One workgroup = 8 waves (WM x WN), tile BM = 32*WM rows x BN = 32*NF*WN columns, 1 workgroup per CU:
+//   * packed weights (the HBM stream, read once): 8 rows x 128 B = 8 FULL cache lines per wave
+//     instruction, global -> VGPR -> LDS one 256-k stage ahead (two LDS stages, XOR-swizzled so the
+//     fragment reads are bank-conflict-free); read back with one ds_read_b128 per 32 columns x 64 k;
+//     nibbles are unpacked in registers with 3 VALU ops per 8 weights (unpack8) straight into the MFMA
+//     B operand.
+//   * activation limbs (re-read per column tile, served by the XCD's L2): the pre-pass stores them in
+//     MFMA-fragment order, so a wave's A operand for one 32-deep k-step is ONE coalesced 1 KiB
+//     buffer_load_dwordx4 straight into VGPRs -- no LDS round trip, no LDS-DMA (whose ~25 B/clk/CU
+//     ceiling and ~100-cycle issue cost capped the earlier LDS-staged version); a 4-step register ring
+//     keeps 4 k-steps of A in flight per wave.
+//   * every load is an ordinary buffer load, so hipcc's own counted s_waitcnt vmcnt(N) tracks them;
+//     one workgroup barrier per 256-k stage (8 MFMA k-steps).
 //
 // Replaces (reference, CUDA): csrc/quantized_linear_kernel.cu:90-279 (one thread per output,
 // weights re-read per batch row) and csrc/moe_int4_kernel.cu:17-136 (one <<<1,256>>> launch and two
@@ -22,60 +26,78 @@
 #pragma once
 #include "fql_common.h"
 
-template <int L, int WM, int WN, int MF, int NF>
+template <int L, int WM, int WN, int NF>
 struct GemmCfg {
     static constexpr int NW = WM * WN;
     static constexpr int THREADS = 64 * NW;
-    static constexpr int BM = 32 * MF * WM;
+    static constexpr int BM = FQL_MB * WM;
     static constexpr int BN = 32 * NF * WN;
-    static constexpr int A_BYTES = L * BM * FQL_BK;          // per stage
-    static constexpr int B_BYTES = BN * (FQL_BK / 2);        // per stage
-    static constexpr int STAGE = A_BYTES + B_BYTES;
-    static constexpr int CA = A_BYTES / 1024;                // 1 KiB LDS-DMA pieces: 16 rows x 64 B
-    static constexpr int CB = B_BYTES / 1024;                // 32 rows x 32 B
-    static constexpr int CPW = (CA + CB + NW - 1) / NW;      // pieces per wave per stage
-    static_assert(BM % 16 == 0 && BN % 32 == 0, "tile must be whole LDS-DMA pieces");
+    static constexpr int KS = FQL_KB / 32;                   // MFMA k-steps per weight stage (8)
+    static constexpr int D = 4;                              // A prefetch depth in k-steps (register ring)
+    static constexpr int B_STAGE = BN * (FQL_KB / 2);        // bytes of packed weights per stage
+    static constexpr int LDS_BYTES = 2 * B_STAGE;
+    static constexpr int CPWB = BN / 8 / NW;                 // 1 KiB weight pieces per wave per stage
+    static_assert(NW == 8, "8 waves per workgroup");
+    static_assert(KS % D == 0, "ring depth must divide the steps per stage");
+    static_assert(BN % 64 == 0, "weight pieces must divide evenly over the waves");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <int L, int WM, int WN, int MF, int NF>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_i8_kernel(
+__device__ __forceinline__ void wait_lgkmcnt0() { __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14)); }
+
+template <int L, int WM, int WN, int NF>
+__global__ __launch_bounds__(512, 2) void gemm_i8_kernel(
     const int8_t *__restrict__ limbs, const float *__restrict__ delta,
     const int32_t *__restrict__ rowsum, const uint8_t *__restrict__ packed,
     const float *__restrict__ scales, const float *__restrict__ zps, float *__restrict__ out,
     const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
-    int E, int T, int K, int Kp, int N, int n_tiles, int m_slots)
+    int E, int T, int K, int Kp, int MBT, int N, int n_tiles, int m_slots)
 {
-#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (hipcc drops the
-                                      // stub of a template kernel whose body holds LDS-DMA builtins)
-    using C = GemmCfg<L, WM, WN, MF, NF>;
-    __shared__ __attribute__((aligned(16))) char lds[2 * C::STAGE];
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub
+    using C = GemmCfg<L, WM, WN, NF>;
+    constexpr int KS = C::KS, D = C::D;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
 
-    // ---- which tile: (m-slot, n-tile), m-slot major so that workgroups on one XCD share an
-    //      expert's activation panel in that XCD's L2 while each weight byte streams once.
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    // ---- which tile.  Real m-tiles are counted on the device (expert counts live there); the grid is
+    //      sized for the worst case and surplus workgroups (the tail of the grid) exit at once.  Logical
+    //      tile ids are m-tile major and dealt to XCDs in contiguous ranges, so the workgroups of one
+    //      XCD share an expert's activation panel in that XCD's L2 while each weight byte streams once.
+    int m_tiles = m_slots;
+    if (tpe != nullptr) {
+        m_tiles = 0;
+        for (int i = 0; i < E; ++i) {
+            int lo, cnt;
+            expert_range(tpe, offs, i, T, lo, cnt);
+            m_tiles += (cnt + C::BM - 1) / C::BM;
+        }
+        if (m_tiles > m_slots) m_tiles = m_slots;        // overlapping ranges: stay inside the grid
+    }
+    const int n_real = m_tiles * n_tiles;
+    if ((int)blockIdx.x >= n_real) return;
+    const int tile = xcd_remap(blockIdx.x, n_real);
     const int ms = tile / n_tiles;
     const int nt = tile - ms * n_tiles;
 
-    int e = 0, row0 = 0, rows_valid = 0;
+    int e = 0, row0 = 0, rows_valid = 0, prow0 = 0;
     if (tpe == nullptr) {                                   // linear: one group covering all T rows
-        row0 = ms * C::BM;
+        row0 = prow0 = ms * C::BM;
         rows_valid = T - row0;
     } else {                                                // MoE: offsets/counts read on the device
-        int run = 0;
+        int run = 0, pbase = 0;
         bool found = false;
         for (int i = 0; i < E; ++i) {
-            long long lo = offs[i], hi = lo + (long long)tpe[i];
-            lo = lo < 0 ? 0 : lo;
-            hi = hi > T ? T : hi;
-            const int cnt = hi > lo ? (int)(hi - lo) : 0;
+            int lo, cnt;
+            expert_range(tpe, offs, i, T, lo, cnt);
             const int tiles = (cnt + C::BM - 1) / C::BM;
             if (!found && ms < run + tiles) {
                 found = true;
                 e = i;
-                row0 = (int)lo + (ms - run) * C::BM;
+                row0 = lo + (ms - run) * C::BM;
+                prow0 = pbase + (ms - run) * C::BM;
                 rows_valid = cnt - (ms - run) * C::BM;
             }
             run += tiles;
+            pbase += (cnt + FQL_MB - 1) / FQL_MB * FQL_MB;
         }
         if (!found) return;
     }
@@ -88,102 +110,138 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_i8_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave - wm * WN;
     const int l31 = lane & 31, g = lane >> 5;
+    const bool active = wm * FQL_MB < rows_valid;           // waves past the expert's last row only help stage weights
 
-    // ---- buffer descriptors (bounds-checked: rows past T / N and the K tail read as zero)
+    // ---- buffer descriptors (bounds-checked: weight rows past N and the K tail read as zero)
+    const int KB = Kp / FQL_KB;
     const size_t wbytes = (size_t)N * (size_t)(K >> 1);
-    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)limbs, 0, (int)((size_t)L * T * Kp), 0x00020000);
-    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)limbs, 0, (int)((size_t)L * KB * MBT * 8192), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(packed + (size_t)e * wbytes), 0, (int)wbytes, 0x00020000);
 
-    // ---- per-lane source offsets of this wave's LDS-DMA pieces (constant over the K loop)
-    int voff[C::CPW];
+    // ---- A operand: limbs[l][kb][mb][ks][lane][16 B]; this wave's row block is mb
+    const int mb = (prow0 >> 5) + wm;
+    int aoff[L];
 #pragma unroll
-    for (int i = 0; i < C::CPW; ++i) {
-        const int c = wave + i * C::NW;
-        if (c < C::CA) {                                    // 16 rows x 64 B of one limb plane
-            const int l = c / (C::BM / 16), cj = c - l * (C::BM / 16);
-            const int rr = lane >> 2, cs = lane & 3;
-            const int lc = cs ^ ((rr >> 2) & 3);            // source-side swizzle
-            voff[i] = (l * T + row0 + cj * 16 + rr) * Kp + lc * 16;
-        } else {                                            // 32 weight rows x 32 B
-            const int cb = c - C::CA;
-            const int nn = lane >> 1, hs = lane & 1;
-            const int lh = hs ^ ((nn >> 3) & 1);
-            voff[i] = (n0 + cb * 32 + nn) * (K >> 1) + lh * 16;
-        }
+    for (int l = 0; l < L; ++l) aoff[l] = ((l * KB) * MBT + mb) * 8192 + lane * 16;
+    const int a_stage = MBT * 8192;                         // bytes between consecutive kb of one limb
+
+    // ---- weight staging: piece p = i*8 + wave covers rows 8p..8p+7, 128 B each (8 full lines)
+    int voffB[C::CPWB], wB[C::CPWB];
+#pragma unroll
+    for (int i = 0; i < C::CPWB; ++i) {
+        const int row = (i * 8 + wave) * 8 + (lane >> 3), ch = lane & 7;
+        voffB[i] = (n0 + row) * (K >> 1) + ch * 16;
+        wB[i] = row * 128 + 16 * (ch ^ ((row >> 1) & 7));   // swizzled LDS image
     }
-
-#define FQL_STAGE_LOAD(kt_, buf_)                                                                          \
-    do {                                                                                                   \
-        char *base_ = lds + (buf_) * C::STAGE;                                                             \
-        _Pragma("unroll") for (int i = 0; i < C::CPW; ++i) {                                               \
-            const int c = wave + i * C::NW;                                                                \
-            if (c < C::CA)                                                                                 \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, LDS_PTR(base_ + c * 1024), 16, voff[i],      \
-                                                         (kt_) * FQL_BK, 0, 0);                            \
-            else if (c < C::CA + C::CB)                                                                    \
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, LDS_PTR(base_ + c * 1024), 16, voff[i],      \
-                                                         (kt_) * (FQL_BK / 2), 0, 0);                      \
-        }                                                                                                  \
-    } while (0)
-
-    v16i acc[L][MF][NF];
-#pragma unroll
-    for (int l = 0; l < L; ++l)
-#pragma unroll
-        for (int i = 0; i < MF; ++i)
-#pragma unroll
-            for (int j = 0; j < NF; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[l][i][j][r] = 0;
-
-    // ---- fragment read offsets inside a stage
-    int a_off[MF], a_sw[MF], b_off[NF];
-#pragma unroll
-    for (int i = 0; i < MF; ++i) {
-        const int r = (wm * MF + i) * 32 + l31;
-        a_off[i] = r * FQL_BK;
-        a_sw[i] = (r >> 2) & 3;
-    }
+    int rB[NF], swB[NF];
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
         const int n = (wn * NF + j) * 32 + l31;
-        b_off[j] = C::A_BYTES + n * (FQL_BK / 2) + 16 * (g ^ ((n >> 3) & 1));
+        rB[j] = n * 128;
+        swB[j] = (n >> 1) & 7;
     }
 
-    const int KT = (K + FQL_BK - 1) / FQL_BK;
-    FQL_STAGE_LOAD(0, 0);
-    for (int kt = 0; kt < KT; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                       // stage kt landed; everyone is done with the other buffer
-        if (kt + 1 < KT) FQL_STAGE_LOAD(kt + 1, (kt + 1) & 1);
-        const char *sb = lds + (kt & 1) * C::STAGE;
+    v16i acc[L][NF];
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[l][j][r] = 0;
 
-        v4i braw[NF];
+    const int KT = KB;                                       // weight stages (K padded to 256 by the pre-pass)
+    v4i bst[C::CPWB];                                        // weight pieces in flight (global -> VGPR -> LDS)
+    v4i afr[D][L];                                           // A ring: D k-steps ahead
+    v4i braw[NF];
+
+    // ---- prologue: stage 0 of the weights into LDS, stage 1 into registers, A for steps 0..D-1.
+    //      Every prefetch below is UNCONDITIONAL: past the last stage the buffer offsets fall outside the
+    //      descriptors and the loads return zero.  (A load under an `if` makes hipcc's counted vmcnt
+    //      collapse to "wait for almost everything", which throws the prefetch lead away.)
 #pragma unroll
-        for (int j = 0; j < NF; ++j) braw[j] = *reinterpret_cast<const v4i *>(sb + b_off[j]);
+    for (int i = 0; i < C::CPWB; ++i) bst[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], 0, 0);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {          // two 32-deep MFMA k-steps per 64-deep stage
-            v4i bfr[NF];
+    for (int i = 0; i < C::CPWB; ++i) *reinterpret_cast<v4i *>(lds + wB[i]) = bst[i];
 #pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                uint32_t lo0, hi0, lo1, hi1;
-                unpack8((uint32_t)braw[j][2 * s], lo0, hi0);
-                unpack8((uint32_t)braw[j][2 * s + 1], lo1, hi1);
-                bfr[j][0] = (int)lo0; bfr[j][1] = (int)hi0; bfr[j][2] = (int)lo1; bfr[j][3] = (int)hi1;
-            }
+    for (int i = 0; i < C::CPWB; ++i) bst[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], FQL_KB / 2, 0);
+
+    if (active) {
 #pragma unroll
-            for (int l = 0; l < L; ++l)
+        for (int s = 0; s < D; ++s)
 #pragma unroll
-                for (int i = 0; i < MF; ++i) {
-                    const v4i afr = *reinterpret_cast<const v4i *>(
-                        sb + l * (C::BM * FQL_BK) + a_off[i] + 16 * ((2 * g + s) ^ a_sw[i]));
+            for (int l = 0; l < L; ++l) afr[s][l] = __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff[l], s * 1024, 0);
+        wait_lgkmcnt0();
+        __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < KT; ++kt) {
+            const char *sb = lds + (kt & 1) * C::B_STAGE;
+            char *nb = lds + ((kt + 1) & 1) * C::B_STAGE;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks == 0) {
+                    // the other LDS stage was released by the barrier that ended stage kt-1: park stage kt+1
+                    // there now, then refill the staging registers with stage kt+2 (a full stage of lead).
+#pragma unroll
+                    for (int i = 0; i < C::CPWB; ++i) *reinterpret_cast<v4i *>(nb + wB[i]) = bst[i];
+#pragma unroll
+                    for (int i = 0; i < C::CPWB; ++i)
+                        bst[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], (kt + 2) * (FQL_KB / 2), 0);
+                }
+                const int v = ks >> 1, b = ks & 1;
+                if (b == 0) {
 #pragma unroll
                     for (int j = 0; j < NF; ++j)
-                        acc[l][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr, bfr[j], acc[l][i][j], 0, 0, 0);
+                        braw[j] = *reinterpret_cast<const v4i *>(sb + rB[j] + 16 * ((2 * v + g) ^ swB[j]));
                 }
+                v4i bfr[NF];
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    uint32_t lo0, hi0, lo1, hi1;
+                    unpack8((uint32_t)braw[j][2 * b], lo0, hi0);
+                    unpack8((uint32_t)braw[j][2 * b + 1], lo1, hi1);
+                    bfr[j][0] = (int)lo0; bfr[j][1] = (int)hi0; bfr[j][2] = (int)lo1; bfr[j][3] = (int)hi1;
+                }
+#if defined(FQL_ABLATE) && FQL_ABLATE == 1
+#pragma unroll
+                for (int l = 0; l < L; ++l) asm volatile("" ::"v"(afr[ks % D][l]));
+#pragma unroll
+                for (int j = 0; j < NF; ++j) asm volatile("" ::"v"(bfr[j]));
+#else
+#pragma unroll
+                for (int l = 0; l < L; ++l)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+                        acc[l][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[ks % D][l], bfr[j], acc[l][j], 0, 0, 0);
+#endif
+                // refill the ring slot just consumed with the A fragments D steps ahead
+                const int nks = ks + D;
+#pragma unroll
+                for (int l = 0; l < L; ++l)
+                    afr[ks % D][l] = __builtin_amdgcn_raw_buffer_load_b128(
+                        rsA, aoff[l], (kt + nks / KS) * a_stage + (nks % KS) * 1024, 0);
+                // pin the software pipeline: without this the machine scheduler sinks the prefetch loads
+                // down to their use D steps later (load; s_waitcnt vmcnt(0); mfma) to save registers.
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            wait_lgkmcnt0();                   // my LDS writes of stage kt+1 are done, my reads of stage kt too
+            __builtin_amdgcn_s_barrier();
         }
+    } else {
+        // waves past the expert's last row: only help stage the weights and keep the barriers in step
+        wait_lgkmcnt0();
+        __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < KT; ++kt) {
+            char *nb = lds + ((kt + 1) & 1) * C::B_STAGE;
+#pragma unroll
+            for (int i = 0; i < C::CPWB; ++i) *reinterpret_cast<v4i *>(nb + wB[i]) = bst[i];
+#pragma unroll
+            for (int i = 0; i < C::CPWB; ++i)
+                bst[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], (kt + 2) * (FQL_KB / 2), 0);
+            wait_lgkmcnt0();
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
     }
 
     // ---- epilogue: fold zero-point, combine limbs, scale.  C/D layout of the 32x32 MFMA:
@@ -198,28 +256,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_i8_kernel(
         zp[j] = ok ? zps[(size_t)e * N + col[j]] : 0.0f;
     }
 #pragma unroll
-    for (int i = 0; i < MF; ++i)
+    for (int r = 0; r < 16; ++r) {
+        const int rl = wm * FQL_MB + (r & 3) + 8 * (r >> 2) + 4 * g;
+        if (rl >= rows_valid) continue;
+        const int t = row0 + rl;
+        const float d = delta[t];
+        float rs[L];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rl = (wm * MF + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-            if (rl >= rows_valid) continue;
-            const int t = row0 + rl;
-            const float d = delta[t];
-            float rs[L];
+        for (int l = 0; l < L; ++l) rs[l] = (float)rowsum[(size_t)l * T + t];
 #pragma unroll
-            for (int l = 0; l < L; ++l) rs[l] = (float)rowsum[(size_t)l * T + t];
+        for (int j = 0; j < NF; ++j) {
+            if (col[j] >= N) continue;
+            float tot = 0.0f;
 #pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                if (col[j] >= N) continue;
-                float tot = 0.0f;
-#pragma unroll
-                for (int l = L - 1; l >= 0; --l) {
-                    const float c = fmaf(-zp[j], rs[l], (float)acc[l][i][j][r]);
-                    tot = fmaf(tot, 256.0f, c);
-                }
-                out[(size_t)t * N + col[j]] = (tot * d) * sc[j];
+            for (int l = L - 1; l >= 0; --l) {
+                const float c = fmaf(-zp[j], rs[l], (float)acc[l][j][r]);
+                tot = fmaf(tot, 256.0f, c);
             }
+            out[(size_t)t * N + col[j]] = (tot * d) * sc[j];
         }
-#undef FQL_STAGE_LOAD
+    }
 #endif  // __HIP_DEVICE_COMPILE__
 }

@@ -13,7 +13,10 @@ namespace {
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline size_t round16(size_t v) { return (v + 15) & ~(size_t)15; }
-inline int padded_k(int K) { return (K + FQL_KPAD - 1) / FQL_KPAD * FQL_KPAD; }
+inline int padded_k(int K) { return (K + FQL_KB - 1) / FQL_KB * FQL_KB; }
+// 32-row blocks of the limb workspace: every expert starts on a block boundary (<= 31 pad rows each) and a
+// tile may run up to 128 rows past the last expert.
+inline int row_blocks(int T, int E) { return (T + FQL_MB * E + 128 + FQL_MB - 1) / FQL_MB; }
 
 inline int limbs_of(int precision)
 {
@@ -29,10 +32,12 @@ struct Workspace {
     size_t bytes;
 };
 
-inline Workspace carve(void *base, int L, int T, int Kp)
+inline size_t limb_bytes(int L, int T, int E, int Kp) { return (size_t)L * (Kp / FQL_KB) * row_blocks(T, E) * 8192; }
+
+inline Workspace carve(void *base, int L, int T, int E, int Kp)
 {
     Workspace w;
-    const size_t lb = round16((size_t)L * T * Kp);
+    const size_t lb = round16(limb_bytes(L, T, E, Kp));
     const size_t db = round16((size_t)T * sizeof(float));
     const size_t rb = round16((size_t)L * T * sizeof(int32_t));
     char *p = static_cast<char *>(base);
@@ -43,46 +48,83 @@ inline Workspace carve(void *base, int L, int T, int Kp)
     return w;
 }
 
-// MFMA tile configuration (see fql_gemm_i8.h): 8 waves as 4(M) x 2(N), 32x64 outputs per wave
-// per limb -> 128 x 128 tile, 2 workgroups per CU.
-constexpr int CFG_WM = 4, CFG_WN = 2, CFG_MF = 1, CFG_NF = 2;
-constexpr int CFG_BM = 32 * CFG_MF * CFG_WM, CFG_BN = 32 * CFG_NF * CFG_WN;
+// ---- MFMA tile configurations (see fql_gemm_i8.h): 8 waves as WM x WN, NF 32-column fragments per wave.
+struct TileShape { int bm, bn; };
+#define FQL_CFG_LIST(X)  \
+    X(0, 4, 2, 3)        /* 128 x 192 */ \
+    X(1, 4, 2, 2)        /* 128 x 128 */ \
+    X(2, 4, 2, 4)        /* 128 x 256 */ \
+    X(3, 2, 4, 2)        /*  64 x 256 */ \
+    X(4, 2, 4, 1)        /*  64 x 128 */ \
+    X(5, 1, 8, 1)        /*  32 x 256 */
+constexpr int FQL_NUM_CFG = 6;
+constexpr int FQL_DEFAULT_CFG = 0;
 
 // The MFMA path addresses its operands through 32-bit buffer offsets.
-inline bool mfma_addressable(int L, int T, int K, int N)
+inline bool mfma_addressable(int L, int T, int E, int K, int N)
 {
-    const size_t a = (size_t)L * ((size_t)T + CFG_BM) * (size_t)padded_k(K);
-    const size_t b = ((size_t)N + CFG_BN) * (size_t)(K >> 1);
+    const size_t a = limb_bytes(L, T, E, padded_k(K));
+    const size_t b = ((size_t)N + 256) * (size_t)(K >> 1);
     return a < ((size_t)1 << 31) && b < ((size_t)1 << 31);
 }
 
-inline bool mfma_eligible(int L, int T, int K, int N, const uint8_t *packed)
+inline bool mfma_eligible(int L, int T, int E, int K, int N, const uint8_t *packed)
 {
-    return (K % 32 == 0) && aligned16(packed) && mfma_addressable(L, T, K, N);
+    return (K % 32 == 0) && aligned16(packed) && mfma_addressable(L, T, E, K, N);
 }
 
 template <int L>
-int launch_act_quant(const float *x, const Workspace &w, int T, int K, int Kp, float *out, int N,
+int launch_act_quant(const float *x, const Workspace &w, int T, int K, int Kp, int MBT, float *out, int N,
                      const int32_t *tpe, const int32_t *offs, int E, hipStream_t st)
 {
     hipLaunchKernelGGL((act_quant_kernel<L>), dim3(T), dim3(256), 0, st, x, w.limbs, w.delta, w.rowsum, T,
-                       K, Kp, out, N, tpe, offs, E);
+                       K, Kp, MBT, out, N, tpe, offs, E);
+    return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
+}
+
+template <int L, int WM, int WN, int NF>
+int launch_gemm_cfg(const Workspace &w, const uint8_t *packed, const float *scales, const float *zps,
+                    float *out, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT, int N,
+                    hipStream_t st)
+{
+    using C = GemmCfg<L, WM, WN, NF>;
+    auto kern = gemm_i8_kernel<L, WM, WN, NF>;
+    static bool attr_set = false;           // idempotent; a race only repeats the same call
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                C::LDS_BYTES) != hipSuccess)
+            return FQL_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int n_tiles = (N + C::BN - 1) / C::BN;
+    const int m_slots = (tpe == nullptr) ? (T + C::BM - 1) / C::BM : T / C::BM + E;
+    const long long blocks = (long long)n_tiles * m_slots;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return FQL_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, w.limbs, w.delta, w.rowsum,
+                       packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
 template <int L>
-int launch_gemm(const Workspace &w, const uint8_t *packed, const float *scales, const float *zps,
-                float *out, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int N,
+int launch_gemm(int cfg, const Workspace &w, const uint8_t *packed, const float *scales, const float *zps,
+                float *out, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT, int N,
                 hipStream_t st)
 {
-    const int n_tiles = (N + CFG_BN - 1) / CFG_BN;
-    const int m_slots = (tpe == nullptr) ? (T + CFG_BM - 1) / CFG_BM : T / CFG_BM + E;
-    const long long blocks = (long long)n_tiles * m_slots;
-    if (blocks <= 0 || blocks > 0x7fffffffLL) return FQL_ERR_BAD_SHAPE;
-    hipLaunchKernelGGL((gemm_i8_kernel<L, CFG_WM, CFG_WN, CFG_MF, CFG_NF>), dim3((unsigned)blocks),
-                       dim3(64 * CFG_WM * CFG_WN), 0, st, w.limbs, w.delta, w.rowsum, packed, scales, zps, out,
-                       tpe, offs, E, T, K, Kp, N, n_tiles, m_slots);
-    return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
+    switch (cfg) {
+#define X(id, wm, wn, nf)                                                                                     \
+    case id:                                                                                                  \
+        return launch_gemm_cfg<L, wm, wn, nf>(w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, st);
+        FQL_CFG_LIST(X)
+#undef X
+    default: return FQL_ERR_BAD_SHAPE;
+    }
+}
+
+// Heuristic tile choice for the product path (tuned on MI355X).
+inline int choose_cfg(int L, int E, int T, int K, int N, bool grouped)
+{
+    (void)L; (void)E; (void)T; (void)K; (void)N; (void)grouped;
+    return FQL_DEFAULT_CFG;
 }
 
 int run_mfma(int L, const float *x, const uint8_t *packed, const float *scales, const float *zps, float *out,
@@ -90,19 +132,21 @@ int run_mfma(int L, const float *x, const uint8_t *packed, const float *scales, 
              size_t workspace_bytes, hipStream_t st)
 {
     const int Kp = padded_k(K);
+    const int MBT = row_blocks(T, E);
     if (workspace == nullptr || !aligned16(workspace)) return FQL_ERR_WORKSPACE;
-    const Workspace w = carve(workspace, L, T, Kp);
+    const Workspace w = carve(workspace, L, T, E, Kp);
     if (workspace_bytes < w.bytes) return FQL_ERR_WORKSPACE;
     float *zero_out = (tpe != nullptr) ? out : nullptr;
+    const int cfg = choose_cfg(L, E, T, K, N, tpe != nullptr);
     int rc;
     if (L == 2) {
-        rc = launch_act_quant<2>(x, w, T, K, Kp, zero_out, N, tpe, offs, E, st);
+        rc = launch_act_quant<2>(x, w, T, K, Kp, MBT, zero_out, N, tpe, offs, E, st);
         if (rc != FQL_OK) return rc;
-        return launch_gemm<2>(w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, N, st);
+        return launch_gemm<2>(cfg, w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, st);
     }
-    rc = launch_act_quant<3>(x, w, T, K, Kp, zero_out, N, tpe, offs, E, st);
+    rc = launch_act_quant<3>(x, w, T, K, Kp, MBT, zero_out, N, tpe, offs, E, st);
     if (rc != FQL_OK) return rc;
-    return launch_gemm<3>(w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, N, st);
+    return launch_gemm<3>(cfg, w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, st);
 }
 
 int run_generic(const float *x, const uint8_t *packed, const float *scales, const float *zps, float *out,
@@ -164,16 +208,16 @@ size_t fql_linear_workspace_bytes(int B, int K, int N, int precision)
     (void)N;
     const int L = limbs_of(precision);
     if (L < 0 || B <= 4 || K <= 0 || (K % 32) != 0) return 0;
-    Workspace w = carve(nullptr, L, B, padded_k(K));
+    Workspace w = carve(nullptr, L, B, 1, padded_k(K));
     return w.bytes;
 }
 
 size_t fql_moe_workspace_bytes(int E, int T, int K, int N, int precision)
 {
-    (void)E; (void)N;
+    (void)N;
     const int L = limbs_of(precision);
-    if (L < 0 || T <= 0 || K <= 0 || (K % 32) != 0) return 0;
-    Workspace w = carve(nullptr, L, T, padded_k(K));
+    if (L < 0 || T <= 0 || E <= 0 || K <= 0 || (K % 32) != 0) return 0;
+    Workspace w = carve(nullptr, L, T, E, padded_k(K));
     return w.bytes;
 }
 
@@ -202,7 +246,7 @@ int fql_linear_fwd_f32(const float *x, const uint8_t *packed, const float *scale
         }
         return run_generic(x, packed, scales, zps, out, nullptr, nullptr, 1, B, K, N, st);
     }
-    if (mfma_eligible(L, B, K, N, packed))
+    if (mfma_eligible(L, B, 1, K, N, packed))
         return run_mfma(L, x, packed, scales, zps, out, nullptr, nullptr, 1, B, K, N, workspace, workspace_bytes, st);
     return run_generic(x, packed, scales, zps, out, nullptr, nullptr, 1, B, K, N, st);
 }
@@ -223,7 +267,7 @@ int fql_moe_fwd_f32(const uint8_t *packed, const float *scales, const float *zps
     }
     if (!packed || !scales || !zps || !inputs || !tokens_per_expert || !input_offsets) return FQL_ERR_NULL_POINTER;
     if (E > 65535) return FQL_ERR_BAD_SHAPE;
-    if (mfma_eligible(L, T, K, N, packed))
+    if (mfma_eligible(L, T, E, K, N, packed))
         return run_mfma(L, inputs, packed, scales, zps, out, tokens_per_expert, input_offsets, E, T, K, N,
                         workspace, workspace_bytes, st);
     return run_generic(inputs, packed, scales, zps, out, tokens_per_expert, input_offsets, E, T, K, N, st);
@@ -253,20 +297,89 @@ int fql_dequantize_f32(const uint8_t *packed, const float *scales, const float *
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
-int fql_act_quant_f32(const float *x, int8_t *limbs, float *delta, int32_t *rowsum, int T, int K, int precision,
-                      void *stream)
+size_t fql_act_limb_bytes(int T, int E, int K, int precision)
+{
+    const int L = limbs_of(precision);
+    if (L < 0 || T <= 0 || E <= 0 || K <= 0) return 0;
+    return limb_bytes(L, T, E, padded_k(K));
+}
+
+int fql_act_quant_f32(const float *x, int8_t *limbs, float *delta, int32_t *rowsum,
+                      const int32_t *tokens_per_expert, const int32_t *input_offsets, int E, int T, int K,
+                      int precision, void *stream)
 {
     const int L = limbs_of(precision);
     if (L < 0) return FQL_ERR_BAD_PRECISION;
-    if (T < 0 || K <= 0) return FQL_ERR_BAD_SHAPE;
+    if (T < 0 || K <= 0 || E <= 0) return FQL_ERR_BAD_SHAPE;
     if (T == 0) return FQL_OK;
     if (!x || !limbs || !delta || !rowsum) return FQL_ERR_NULL_POINTER;
-    if ((reinterpret_cast<uintptr_t>(limbs) & 7) != 0) return FQL_ERR_ALIGNMENT;
+    if ((tokens_per_expert == nullptr) != (input_offsets == nullptr)) return FQL_ERR_NULL_POINTER;
+    if (tokens_per_expert == nullptr && E != 1) return FQL_ERR_BAD_SHAPE;
+    if (!aligned16(limbs)) return FQL_ERR_ALIGNMENT;
     Workspace w;
     w.limbs = limbs; w.delta = delta; w.rowsum = rowsum; w.bytes = 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (L == 2) return launch_act_quant<2>(x, w, T, K, padded_k(K), nullptr, 0, nullptr, nullptr, 0, st);
-    return launch_act_quant<3>(x, w, T, K, padded_k(K), nullptr, 0, nullptr, nullptr, 0, st);
+    const int Kp = padded_k(K), MBT = row_blocks(T, E);
+    if (L == 2) return launch_act_quant<2>(x, w, T, K, Kp, MBT, nullptr, 0, tokens_per_expert, input_offsets, E, st);
+    return launch_act_quant<3>(x, w, T, K, Kp, MBT, nullptr, 0, tokens_per_expert, input_offsets, E, st);
 }
+
+static int gemm_i8_entry(int cfg, const int8_t *limbs, const float *delta, const int32_t *rowsum,
+                         const uint8_t *packed, const float *scales, const float *zps,
+                         const int32_t *tokens_per_expert, const int32_t *input_offsets, float *out, int E, int T,
+                         int K, int N, int precision, void *stream)
+{
+    const int L = limbs_of(precision);
+    if (L < 0) return FQL_ERR_BAD_PRECISION;
+    if (E <= 0 || T < 0 || K <= 0 || N < 0) return FQL_ERR_BAD_SHAPE;
+    if (K & 1) return FQL_ERR_ODD_K;
+    if (T == 0 || N == 0) return FQL_OK;
+    if (!limbs || !delta || !rowsum || !packed || !scales || !zps || !out) return FQL_ERR_NULL_POINTER;
+    if ((tokens_per_expert == nullptr) != (input_offsets == nullptr)) return FQL_ERR_NULL_POINTER;
+    if (tokens_per_expert == nullptr && E != 1) return FQL_ERR_BAD_SHAPE;
+    if ((K % 32) != 0 || !aligned16(packed) || !aligned16(limbs)) return FQL_ERR_ALIGNMENT;
+    if (!mfma_addressable(L, T, E, K, N)) return FQL_ERR_BAD_SHAPE;
+    if (cfg < 0) cfg = choose_cfg(L, E, T, K, N, tokens_per_expert != nullptr);
+    if (cfg >= FQL_NUM_CFG) return FQL_ERR_BAD_SHAPE;
+    Workspace w;
+    w.limbs = const_cast<int8_t *>(limbs);
+    w.delta = const_cast<float *>(delta);
+    w.rowsum = const_cast<int32_t *>(rowsum);
+    w.bytes = 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int Kp = padded_k(K), MBT = row_blocks(T, E);
+    if (L == 2)
+        return launch_gemm<2>(cfg, w, packed, scales, zps, out, tokens_per_expert, input_offsets, E, T, K, Kp, MBT, N, st);
+    return launch_gemm<3>(cfg, w, packed, scales, zps, out, tokens_per_expert, input_offsets, E, T, K, Kp, MBT, N, st);
+}
+
+int fql_gemm_i8_f32(const int8_t *limbs, const float *delta, const int32_t *rowsum, const uint8_t *packed,
+                    const float *scales, const float *zps, const int32_t *tokens_per_expert,
+                    const int32_t *input_offsets, float *out, int E, int T, int K, int N, int precision,
+                    void *stream)
+{
+    return gemm_i8_entry(-1, limbs, delta, rowsum, packed, scales, zps, tokens_per_expert, input_offsets, out, E, T,
+                         K, N, precision, stream);
+}
+
+// Tuning hook (not part of the public header): the same call with an explicit tile configuration id.
+FQL_API int fql_tune_gemm_i8_f32(int cfg, const int8_t *limbs, const float *delta, const int32_t *rowsum,
+                                 const uint8_t *packed, const float *scales, const float *zps,
+                                 const int32_t *tokens_per_expert, const int32_t *input_offsets, float *out, int E,
+                                 int T, int K, int N, int precision, void *stream)
+{
+    if (cfg < 0 || cfg >= FQL_NUM_CFG) return FQL_ERR_BAD_SHAPE;
+    return gemm_i8_entry(cfg, limbs, delta, rowsum, packed, scales, zps, tokens_per_expert, input_offsets, out, E, T,
+                         K, N, precision, stream);
+}
+
+FQL_API int fql_tune_num_configs(void) { return FQL_NUM_CFG; }
+
+#if defined(FQL_STAMP)
+FQL_API int fql_tune_read_stamps(unsigned long long *dst)      // diagnostic build only; synchronises
+{
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(fql_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 }  // extern "C"

@@ -166,20 +166,54 @@ def dequantize_forward(packed_weights, scales, zero_points):
     return w
 
 
-def act_quant(x, precision="default"):
-    """Activation pre-pass of the MFMA path (introspection for tests)."""
+def act_quant(x, precision="default", tokens_per_expert=None, input_offsets=None):
+    """Phase 1 of the MFMA path: float32 rows -> int8 limbs in MFMA-fragment order (+ delta, rowsum).
+    Pass the device-side expert arrays for a grouped (MoE) layout, or neither for one group."""
     if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2:
         raise RuntimeError("x must be a CUDA float32 [T,K] tensor")
     x = x.contiguous()
     T, K = x.shape
     prec = _precision(precision)
     nl = 3 if prec == 0 else prec
-    Kp = _native.lib().fql_act_padded_k(K)
-    limbs = torch.empty((nl, T, Kp), dtype=torch.int8, device=x.device)
+    grouped = tokens_per_expert is not None
+    E = tokens_per_expert.numel() if grouped else 1
+    L = _native.lib()
+    limbs = torch.zeros(L.fql_act_limb_bytes(T, E, K, prec), dtype=torch.int8, device=x.device)
     delta = torch.empty((T,), dtype=torch.float32, device=x.device)
     rowsum = torch.empty((nl, T), dtype=torch.int32, device=x.device)
     with torch.cuda.device(x.device):
-        rc = _native.lib().fql_act_quant_f32(x.data_ptr(), limbs.data_ptr(), delta.data_ptr(), rowsum.data_ptr(),
-                                             T, K, prec, _stream_ptr(x.device))
+        rc = L.fql_act_quant_f32(x.data_ptr(), limbs.data_ptr(), delta.data_ptr(), rowsum.data_ptr(),
+                                 tokens_per_expert.data_ptr() if grouped else None,
+                                 input_offsets.data_ptr() if grouped else None, E, T, K, prec,
+                                 _stream_ptr(x.device))
     _native.check(rc, "fql_act_quant_f32")
     return limbs, delta, rowsum
+
+
+def gemm_i8(limbs, delta, rowsum, packed_weights, scales, zero_points, tokens_per_expert=None,
+            input_offsets=None, precision="default", out=None):
+    """Phase 2 of the MFMA path: grouped INT4 x INT8-limb GEMM over pre-converted activations
+    (``act_quant`` output, produced with the same expert arrays).  ``packed_weights`` [N,K/2] (one
+    group) or [E,N,K/2] with device-side ``tokens_per_expert`` / ``input_offsets``."""
+    T = delta.numel()
+    grouped = packed_weights.dim() == 3
+    E = packed_weights.shape[0] if grouped else 1
+    N, K2 = packed_weights.shape[-2:]
+    K = 2 * K2
+    prec = _precision(precision)
+    if (3 if prec == 0 else prec) != rowsum.shape[0]:
+        raise RuntimeError("limb count does not match precision")
+    if limbs.numel() < _native.lib().fql_act_limb_bytes(T, E, K, prec):
+        raise RuntimeError("limbs were not produced for this T, E, K")
+    dev = limbs.device
+    if out is None:
+        out = torch.zeros((T, N), dtype=torch.float32, device=dev) if grouped else \
+            torch.empty((T, N), dtype=torch.float32, device=dev)
+    tpe_ptr = tokens_per_expert.data_ptr() if grouped else None
+    off_ptr = input_offsets.data_ptr() if grouped else None
+    with torch.cuda.device(dev):
+        rc = _native.lib().fql_gemm_i8_f32(limbs.data_ptr(), delta.data_ptr(), rowsum.data_ptr(),
+                                           packed_weights.data_ptr(), scales.data_ptr(), zero_points.data_ptr(),
+                                           tpe_ptr, off_ptr, out.data_ptr(), E, T, K, N, prec, _stream_ptr(dev))
+    _native.check(rc, "fql_gemm_i8_f32")
+    return out

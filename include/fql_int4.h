@@ -119,16 +119,36 @@ FQL_API int fql_dequantize_f32(const uint8_t *packed, const float *scales, const
                        int N, int K, void *stream);
 
 /* ---------------------------------------------------------------------------------------
- * Introspection for tests: the activation pre-pass of the MFMA path.
- *   limbs  [precision][T][Kp] int8 (Kp = fql_act_padded_k(K)), k permuted inside every aligned
- *          group of 8 as (0,2,4,6,1,3,5,7) to match the in-register nibble unpack order
- *   delta  [T] float32 (power of two), rowsum [precision][T] int32
- *   x[t][k] ~= delta[t] * sum_l 256^l * limb_l[t][k]
+ * Phase 1 of the MFMA path on its own: the activation pre-pass (also the tests' window into it).
+ *   x[t][k] ~= delta[t] * sum_l 256^l * a_l[t][k],  a_l signed 8-bit ("limbs"), delta a power of two
+ *   limbs   fql_act_limb_bytes(T, E, K, precision) bytes, 16-byte aligned, in MFMA-fragment order:
+ *           [limb][k / 256][padded_row / 32][k-step 0..7][lane 0..63][16 B]  (see csrc/fql_act_quant.h;
+ *           expert e's rows start at padded row sum_{e'<e} roundup(cnt_e', 32); K is zero-padded to
+ *           fql_act_padded_k(K))
+ *   delta   [T] float32, rowsum [precision][T] int32 (sum over k of each limb)
+ *   tokens_per_expert / input_offsets: device arrays as in fql_moe_fwd_f32, or both NULL with E = 1
+ *   for one group covering all T rows.  Rows covered by no expert are skipped.
  * ------------------------------------------------------------------------------------- */
 FQL_API int fql_act_padded_k(int K);
 
-FQL_API int fql_act_quant_f32(const float *x, int8_t *limbs, float *delta, int32_t *rowsum, int T, int K,
-                      int precision, void *stream);
+FQL_API size_t fql_act_limb_bytes(int T, int E, int K, int precision);
+
+FQL_API int fql_act_quant_f32(const float *x, int8_t *limbs, float *delta, int32_t *rowsum,
+                              const int32_t *tokens_per_expert, const int32_t *input_offsets, int E,
+                              int T, int K, int precision, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Phase 2 of the MFMA path on its own: the grouped INT4 x INT8-limb GEMM over activations that
+ * fql_act_quant_f32 already converted (fql_linear_fwd_f32 / fql_moe_fwd_f32 = phase 1 + phase 2
+ * back to back).  Lets a caller fuse its own gather/dispatch into phase 1, and lets bench.py
+ * time the dominant kernel alone.  The expert arrays must be the ones phase 1 was given (they fix
+ * the limb layout); tokens_per_expert == NULL means one group covering all T rows (E must be 1).  Requires K % 32 == 0 and a 16-byte aligned `packed`
+ * (FQL_ERR_ALIGNMENT otherwise).  Rows covered by no expert are left untouched.
+ * ------------------------------------------------------------------------------------- */
+FQL_API int fql_gemm_i8_f32(const int8_t *limbs, const float *delta, const int32_t *rowsum,
+                            const uint8_t *packed, const float *scales, const float *zps,
+                            const int32_t *tokens_per_expert, const int32_t *input_offsets,
+                            float *out, int E, int T, int K, int N, int precision, void *stream);
 
 #ifdef __cplusplus
 }
