@@ -45,6 +45,10 @@ struct GemmCfg {
 
 __device__ __forceinline__ void wait_lgkmcnt0() { __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14)); }
 
+#if defined(FQL_STAMP)
+__device__ unsigned long long fql_stamps[64];        // diagnostic build only
+#endif
+
 template <int L, int WM, int WN, int NF>
 __global__ __launch_bounds__(512, 2) void gemm_i8_kernel(
     const int8_t *__restrict__ limbs, const float *__restrict__ delta,
@@ -167,6 +171,9 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_kernel(
 #pragma unroll
     for (int i = 0; i < C::CPWB; ++i) bst[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], FQL_KB / 2, 0);
 
+#if defined(FQL_STAMP)
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (active) {
 #pragma unroll
         for (int s = 0; s < D; ++s)
@@ -179,6 +186,7 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_kernel(
             char *nb = lds + ((kt + 1) & 1) * C::B_STAGE;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
+#if !defined(FQL_ABL_NOB)
                 if (ks == 0) {
                     // the other LDS stage was released by the barrier that ended stage kt-1: park stage kt+1
                     // there now, then refill the staging registers with stage kt+2 (a full stage of lead).
@@ -188,8 +196,14 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_kernel(
                     for (int i = 0; i < C::CPWB; ++i)
                         bst[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], (kt + 2) * (FQL_KB / 2), 0);
                 }
+#endif
                 const int v = ks >> 1, b = ks & 1;
-                if (b == 0) {
+#if defined(FQL_ABL_NOBREAD)
+                if (kt == 0 && ks == 0)
+#else
+                if (b == 0)
+#endif
+                {
 #pragma unroll
                     for (int j = 0; j < NF; ++j)
                         braw[j] = *reinterpret_cast<const v4i *>(sb + rB[j] + 16 * ((2 * v + g) ^ swB[j]));
@@ -212,14 +226,16 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_kernel(
                 for (int l = 0; l < L; ++l)
 #pragma unroll
                     for (int j = 0; j < NF; ++j)
-                        acc[l][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afr[ks % D][l], bfr[j], acc[l][j], 0, 0, 0);
+                        acc[l][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bfr[j], afr[ks % D][l], acc[l][j], 0, 0, 0);
 #endif
                 // refill the ring slot just consumed with the A fragments D steps ahead
                 const int nks = ks + D;
+#if !defined(FQL_ABLATE) || FQL_ABLATE != 3
 #pragma unroll
                 for (int l = 0; l < L; ++l)
                     afr[ks % D][l] = __builtin_amdgcn_raw_buffer_load_b128(
                         rsA, aoff[l], (kt + nks / KS) * a_stage + (nks % KS) * 1024, 0);
+#endif
                 // pin the software pipeline: without this the machine scheduler sinks the prefetch loads
                 // down to their use D steps later (load; s_waitcnt vmcnt(0); mfma) to save registers.
                 __builtin_amdgcn_sched_barrier(0);
@@ -244,37 +260,63 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_kernel(
         return;
     }
 
-    // ---- epilogue: fold zero-point, combine limbs, scale.  C/D layout of the 32x32 MFMA:
-    //      col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-    float sc[NF], zp[NF];
-    int col[NF];
+#if defined(FQL_STAMP)
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // ---- epilogue: fold zero-point, combine limbs, scale.  The weights are the MFMA's A operand (rows = n)
+    //      and the activations its B operand (cols = t), so in the 32x32 C/D layout
+    //      (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) every lane owns ONE output
+    //      row t and registers 4q..4q+3 are 4 consecutive output columns: 4 per-row loads per lane and
+    //      16-byte stores.
+    const int rl = wm * FQL_MB + l31;
+    if (rl >= rows_valid) return;
+    const int t = row0 + rl;
+    const float d = delta[t];
+    float rs[L];
 #pragma unroll
-    for (int j = 0; j < NF; ++j) {
-        col[j] = n0 + (wn * NF + j) * 32 + l31;
-        const bool ok = col[j] < N;
-        sc[j] = ok ? scales[(size_t)e * N + col[j]] : 0.0f;
-        zp[j] = ok ? zps[(size_t)e * N + col[j]] : 0.0f;
-    }
+    for (int l = 0; l < L; ++l) rs[l] = (float)rowsum[(size_t)l * T + t];
+    const float *sce = scales + (size_t)e * N;
+    const float *zpe = zps + (size_t)e * N;
+    float *orow = out + (size_t)t * N;
+    const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(sce) & 15) == 0) && ((reinterpret_cast<uintptr_t>(zpe) & 15) == 0);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int rl = wm * FQL_MB + (r & 3) + 8 * (r >> 2) + 4 * g;
-        if (rl >= rows_valid) continue;
-        const int t = row0 + rl;
-        const float d = delta[t];
-        float rs[L];
+    for (int j = 0; j < NF; ++j)
 #pragma unroll
-        for (int l = 0; l < L; ++l) rs[l] = (float)rowsum[(size_t)l * T + t];
+        for (int q = 0; q < 4; ++q) {
+            const int n = n0 + (wn * NF + j) * 32 + 8 * q + 4 * g;
+            if (n >= N) continue;
+            float o[4];
+            if (vec) {                                       // n % 4 == 0 and N % 4 == 0: all four columns exist
+                const v4f s4 = *reinterpret_cast<const v4f *>(sce + n);
+                const v4f z4 = *reinterpret_cast<const v4f *>(zpe + n);
 #pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            if (col[j] >= N) continue;
-            float tot = 0.0f;
+                for (int c = 0; c < 4; ++c) {
+                    float tot = 0.0f;
 #pragma unroll
-            for (int l = L - 1; l >= 0; --l) {
-                const float c = fmaf(-zp[j], rs[l], (float)acc[l][j][r]);
-                tot = fmaf(tot, 256.0f, c);
+                    for (int l = L - 1; l >= 0; --l)
+                        tot = fmaf(tot, 256.0f, fmaf(-z4[c], rs[l], (float)acc[l][j][4 * q + c]));
+                    o[c] = (tot * d) * s4[c];
+                }
+                *reinterpret_cast<v4f *>(orow + n) = v4f{o[0], o[1], o[2], o[3]};
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (n + c >= N) continue;
+                    float tot = 0.0f;
+#pragma unroll
+                    for (int l = L - 1; l >= 0; --l)
+                        tot = fmaf(tot, 256.0f, fmaf(-zpe[n + c], rs[l], (float)acc[l][j][4 * q + c]));
+                    orow[n + c] = (tot * d) * sce[n + c];
+                }
             }
-            out[(size_t)t * N + col[j]] = (tot * d) * sc[j];
         }
+#if defined(FQL_STAMP)
+    if (blockIdx.x == 8 && lane == 0) {
+        const unsigned long long st2 = __builtin_amdgcn_s_memtime(), rt2 = __builtin_amdgcn_s_memrealtime();
+        fql_stamps[wave * 8 + 0] = st1 - st0; fql_stamps[wave * 8 + 1] = rt1 - rt0;
+        fql_stamps[wave * 8 + 2] = st2 - st1; fql_stamps[wave * 8 + 3] = rt2 - rt1;
     }
+#endif
 #endif  // __HIP_DEVICE_COMPILE__
 }

@@ -58,7 +58,6 @@ struct TileShape { int bm, bn; };
     X(4, 2, 4, 1)        /*  64 x 128 */ \
     X(5, 1, 8, 1)        /*  32 x 256 */
 constexpr int FQL_NUM_CFG = 6;
-constexpr int FQL_DEFAULT_CFG = 0;
 
 // The MFMA path addresses its operands through 32-bit buffer offsets.
 inline bool mfma_addressable(int L, int T, int E, int K, int N)
@@ -120,11 +119,30 @@ int launch_gemm(int cfg, const Workspace &w, const uint8_t *packed, const float 
     }
 }
 
-// Heuristic tile choice for the product path (tuned on MI355X).
+// Heuristic tile choice for the product path (MI355X: 256 CUs, one workgroup per CU).
+//   rows per group decide the tile height (32 / 64 / 128-row tiles: a short group must not pay for
+//   128 rows of MFMA work); the tile width is the one that needs the least "rounds x width" of the
+//   256 CUs -- e.g. 8 experts x 128 rows x N = 11008: 128 x 192 tiles give 464 tiles = 2 rounds x 192,
+//   128 x 128 give 688 = 3 rounds x 128 (equal), 128 x 256 give 344 = 2 rounds x 256 (worse).
 inline int choose_cfg(int L, int E, int T, int K, int N, bool grouped)
 {
-    (void)L; (void)E; (void)T; (void)K; (void)N; (void)grouped;
-    return FQL_DEFAULT_CFG;
+    (void)K;
+    const int groups = grouped ? (E > 0 ? E : 1) : 1;
+    const int m = (T + groups - 1) / groups;                 // rows per group if evenly routed
+    if (m <= 32) return 5;                                   //  32 x 256
+    if (m <= 64) return 3;                                   //  64 x 256
+    const int mt = groups * ((m + 127) / 128);
+    struct Cand { int cfg, bn; };
+    const Cand cands[3] = {{0, 192}, {1, 128}, {2, 256}};
+    int best = 0;
+    long long best_cost = -1;
+    for (int i = 0; i < (L == 2 ? 3 : 2); ++i) {             // 128 x 256 needs the 2-limb register budget
+        const long long tiles = (long long)mt * ((N + cands[i].bn - 1) / cands[i].bn);
+        const long long rounds = (tiles + 255) / 256;
+        const long long cost = rounds * (cands[i].bn + 24);  // +24: per-tile prologue / epilogue
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cands[i].cfg; }
+    }
+    return best;
 }
 
 int run_mfma(int L, const float *x, const uint8_t *packed, const float *scales, const float *zps, float *out,

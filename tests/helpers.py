@@ -1,0 +1,89 @@
+"""Shared helpers for the tests (CPU restatements of the library's OWN conventions, and tolerances)."""
+import numpy as np
+
+# ---- stated floating-point tolerances (see DESIGN.md "Numerics") -------------------------------
+# exact mode (3 limbs, 23-bit fixed point per activation row): float32-class.
+EXACT_REL_FRO = 2e-6          # ||got - ref64||_F / ||ref64||_F
+# fast mode (2 limbs, 15-bit fixed point): north_star bound is 1e-3 relative; measured ~3e-5.
+FAST_REL_FRO = 2e-4
+# GEMV / generic float32 FMA paths: summation-order noise only.
+FMA_REL_FRO = 2e-6
+
+
+def rel_fro(got, ref):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    den = np.linalg.norm(ref)
+    return np.linalg.norm(got - ref) / (den if den > 0 else 1.0)
+
+
+def act_limbs_reference(x, L):
+    """numpy restatement of the library's activation pre-pass (csrc/fql_act_quant.h): per row,
+    delta = 2^e with the smallest e such that rint(max|x| / 2^e) <= LIM(L); X = rint(x / delta);
+    balanced base-256 digits a_l in [-128, 127].  Returns (digits [L,T,K] int32, delta [T], rowsum [L,T])."""
+    x = np.asarray(x, dtype=np.float32)
+    T, K = x.shape
+    lim = {1: 127, 2: 127 * 256 + 127, 3: 127 * 65536 + 127 * 256 + 127}[L]
+    digits = np.zeros((L, T, K), dtype=np.int64)
+    delta = np.zeros(T, dtype=np.float32)
+    for t in range(T):
+        m = np.float32(np.abs(x[t]).max()) if K else np.float32(0)
+        if m == 0:
+            e = 0
+        else:
+            _, ex = np.frexp(m)
+            e = max(int(ex) - 1 - (8 * L - 2), -126)
+            if np.rint(np.float32(m) * np.float32(2.0 ** -e)) > lim:
+                e += 1
+        delta[t] = np.float32(2.0 ** e)
+        X = np.rint(x[t].astype(np.float32) * np.float32(2.0 ** -e)).astype(np.int64)
+        for l in range(L):
+            if l == L - 1:
+                d = X
+            else:
+                d = ((X + 128) & 255) - 128
+                X = (X - d) >> 8
+            digits[l, t] = d
+    return digits, delta, digits.sum(axis=2)
+
+
+def decode_limbs(limbs_bytes, L, T, E, K, Kp, counts=None, offsets=None):
+    """Invert the fragment-native layout written by the pre-pass:
+    limbs[l][kb][mb][ks][lane][16 B] -> digits [L, T, Kp] in natural k order."""
+    raw = np.asarray(limbs_bytes).view(np.int8)
+    KB = Kp // 256
+    MBT = raw.size // (L * KB * 8192)
+    arr = raw.reshape(L, KB, MBT, 8, 64, 16)
+    # padded row of every t
+    if counts is None:
+        prow = np.arange(T)
+        covered = np.ones(T, bool)
+    else:
+        prow = np.zeros(T, dtype=np.int64)
+        covered = np.zeros(T, bool)
+        pbase = 0
+        for c, o in zip(counts, offsets):
+            lo, hi = max(int(o), 0), min(int(o) + int(c), T)
+            cnt = max(hi - lo, 0)
+            for t in range(lo, hi):
+                if not covered[t]:
+                    prow[t] = pbase + (t - lo)
+                    covered[t] = True
+            pbase += (cnt + 31) // 32 * 32
+    out = np.zeros((L, T, Kp), dtype=np.int64)
+    perm8 = [0, 2, 4, 6, 1, 3, 5, 7]                         # stored position i holds natural k perm8[i]
+    for t in range(T):
+        if not covered[t]:
+            continue
+        p = int(prow[t])
+        for kb in range(KB):
+            for c in range(8):                               # 32-k chunk of the 256 block
+                v, g = c >> 1, c & 1
+                for b in range(2):
+                    ks = 2 * v + b
+                    sixteen = arr[:, kb, p >> 5, ks, g * 32 + (p & 31), :]      # [L,16]
+                    k0 = kb * 256 + 32 * c + 16 * b
+                    for h in range(2):                       # two groups of 8
+                        for i in range(8):
+                            out[:, t, k0 + 8 * h + perm8[i]] = sixteen[:, 8 * h + i]
+    return out, covered

@@ -1,0 +1,109 @@
+"""Expert-parallel dispatch / combine on CPU: world_size 2 (and 4) over the gloo backend.
+
+The grouped-GEMM step is replaced by a CPU expert function (the package's un-fused
+dequantize-then-matmul), so what is tested is the distributed mechanics of ep.py: counts exchange,
+uneven all-to-all dispatch, regrouping by local expert, the reverse all-to-all and the weighted
+combine.  The result must equal the single-process computation on the same tokens."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _make_problem(E, K, N, tokens, top_k, seed):
+    import fused_int4_amd as fq
+    g = torch.Generator().manual_seed(seed)
+    P, S, Z = [], [], []
+    for _ in range(E):
+        p, s, z = fq.quantize_weights(torch.randn(N, K, generator=g) * 0.05)
+        P.append(p); S.append(s); Z.append(z)
+    x = torch.randn(tokens, K, generator=g)
+    logits = torch.randn(tokens, E, generator=g)
+    w, idx = torch.topk(torch.softmax(logits, -1), top_k, dim=-1)
+    w = w / w.sum(-1, keepdim=True)
+    return torch.stack(P), torch.stack(S), torch.stack(Z), x, idx, w
+
+
+def _expert_fn_factory(P, S, Z):
+    import fused_int4_amd as fq
+
+    def fn(rows, tpe, offs):
+        out = torch.zeros(rows.shape[0], P.shape[1])
+        for e in range(P.shape[0]):
+            c, o = int(tpe[e]), int(offs[e])
+            if c:
+                out[o:o + c] = fq.reference_quantized_linear(rows[o:o + c], P[e], S[e], Z[e])
+        return out
+    return fn
+
+
+def _single_process(P, S, Z, x, idx, w):
+    import fused_int4_amd as fq
+    E, top_k = P.shape[0], idx.shape[1]
+    grouped, tpe, offs, inv = fq.dispatch_grouped(x, idx, E)
+    y = _expert_fn_factory(P, S, Z)(grouped, tpe, offs)
+    return fq.combine_grouped(y, w, inv, top_k)
+
+
+def _worker(rank, world, port, E, K, N, tokens, top_k, seed, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fused_int4_amd.ep import ExpertParallelMoE
+        P, S, Z, x, idx, w = _make_problem(E, K, N, tokens, top_k, seed)
+        per = tokens // world
+        sl = slice(rank * per, (rank + 1) * per)
+        Pl = ExpertParallelMoE.shard(P, rank, world)
+        Sl = ExpertParallelMoE.shard(S, rank, world)
+        Zl = ExpertParallelMoE.shard(Z, rank, world)
+        ep = ExpertParallelMoE(E, expert_fn=_expert_fn_factory(Pl, Sl, Zl), out_features=N)
+        assert ep.experts_per_rank == E // world
+        y = ep(x[sl].contiguous(), idx[sl].contiguous(), w[sl].contiguous())
+        ref = _single_process(P, S, Z, x, idx, w)[sl]
+        ret[rank] = float((y - ref).abs().max())
+        # a rank that routes nothing to some peer / receives nothing from it still works
+        idx2 = torch.full_like(idx[sl], rank * (E // world))          # everything stays local
+        idx2[:, 1] = rank * (E // world) + (1 if E // world > 1 else 0)
+        y2 = ep(x[sl].contiguous(), idx2, w[sl].contiguous())
+        idxf = idx.clone(); idxf[sl] = idx2
+        # only this rank's slice is compared, and its rows only visit local experts
+        ref2 = _single_process(P, S, Z, x[sl], idx2, w[sl])
+        ret[world + rank] = float((y2 - ref2).abs().max())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,E", [(2, 4), (2, 2), (4, 8)])
+def test_expert_parallel_matches_single_process(world, E):
+    mp_ctx = mp.get_context("spawn")
+    ret = mp_ctx.Manager().dict()
+    port = _free_port()
+    procs = [mp_ctx.Process(target=_worker, args=(r, world, port, E, 64, 48, 32, 2, 123, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert len(ret) == 2 * world
+    assert max(ret.values()) < 1e-5, dict(ret)
+
+
+def test_single_rank_path_needs_no_process_group():
+    from fused_int4_amd.ep import ExpertParallelMoE
+    P, S, Z, x, idx, w = _make_problem(4, 32, 24, 10, 2, 5)
+    ep = ExpertParallelMoE(4, expert_fn=_expert_fn_factory(P, S, Z), out_features=24)
+    y = ep(x, idx, w)
+    assert torch.allclose(y, _single_process(P, S, Z, x, idx, w), atol=1e-6)
+    with pytest.raises(ValueError):
+        ExpertParallelMoE(4)           # no weights and no expert_fn

@@ -1,0 +1,436 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X).  Every call goes through the C ABI of
+csrc/libfql_int4.so (via the ctypes shim in ops.py); the checker is the CPU oracle (oracle/) and
+the golden vectors generated from the reference's own Python (tests/golden/).
+
+Bars: bit-exact for the INT4 unpack / index / limb paths and for integer-valued inputs;
+floating-point outputs within the tolerances written in tests/helpers.py, and within the
+reference's own test tolerances (tests/test_correctness.py:218,233,252: atol 1e-3 / 1e-3 / 1e-2)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from helpers import (EXACT_REL_FRO, FAST_REL_FRO, FMA_REL_FRO, rel_fro, act_limbs_reference, decode_limbs)
+from oracle import oracle as O
+from oracle import c_oracle as C
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fq():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import fused_int4_amd as pkg
+    from fused_int4_amd import _native
+    _native.lib()                       # fails loudly if the extension is not built
+    return pkg
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def make_problem(N, K, B, seed, wscale=1.0):
+    rng = np.random.default_rng(seed)
+    w = (rng.standard_normal((N, K)) * wscale).astype(np.float32)
+    x = rng.standard_normal((B, K)).astype(np.float32)
+    p, s, z = O.quantize_weights(w)
+    return x, p, s, z
+
+
+# ------------------------------------------------------------------------------ format helpers
+def test_unpack_bit_exact(fq):
+    from fused_int4_amd import ops
+    rng = np.random.default_rng(0)
+    for shape in [(1, 1), (3, 5), (64, 2048), (7, 33), (11008, 64)]:
+        p = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        got = ops.unpack_nibbles(dev(p)).cpu().numpy()
+        assert np.array_equal(got, O.unpack_nibbles(p)), shape
+        assert np.array_equal(got, C.unpack(p)), shape
+
+
+def test_dequantize_bit_exact(fq):
+    from fused_int4_amd import ops
+    g = load_golden("f1_quant_16x32")
+    got = ops.dequantize_forward(dev(g["packed"]), dev(g["scales"]), dev(g["zero_points"])).cpu().numpy()
+    assert np.array_equal(got, g["dequant"])
+    x, p, s, z = make_problem(300, 1030, 1, 3)
+    got = ops.dequantize_forward(dev(p), dev(s), dev(z)).cpu().numpy()
+    assert np.array_equal(got, O.dequantize_weights(p, s, z))
+    # the package-level API dispatches to the same kernel on GPU tensors
+    got2 = fq.dequantize_weights(dev(p), dev(s), dev(z)).cpu().numpy()
+    assert np.array_equal(got2, got)
+
+
+@pytest.mark.parametrize("L,prec", [(3, "exact"), (2, "fast")])
+def test_activation_limbs_bit_exact(fq, L, prec):
+    """The pre-pass (phase 1) against a numpy restatement of the same fixed-point rule."""
+    from fused_int4_amd import ops
+    rng = np.random.default_rng(5)
+    T, K = 37, 544                                          # K % 256 != 0 -> zero padded; ragged T
+    x = rng.standard_normal((T, K)).astype(np.float32)
+    x[3] = 0.0                                              # all-zero row
+    x[4] *= 1e-30                                           # tiny magnitudes
+    x[5] *= 1e30                                            # huge magnitudes
+    x[6, 7] = 2.0 ** 10                                     # row max exactly a power of two
+    x[7, :] = np.float32(32639.6)                           # rounds above the 2-limb limit -> exponent bump
+    limbs, delta, rowsum = ops.act_quant(dev(x), precision=prec)
+    Kp = 768
+    dig, covered = decode_limbs(limbs.cpu().numpy(), L, T, 1, K, Kp)
+    ref_dig, ref_delta, ref_sum = act_limbs_reference(x, L)
+    assert covered.all()
+    assert np.array_equal(delta.cpu().numpy(), ref_delta)
+    assert np.array_equal(dig[:, :, :K], ref_dig)
+    assert (dig[:, :, K:] == 0).all()
+    assert np.array_equal(rowsum.cpu().numpy(), ref_sum)
+    assert dig.min() >= -128 and dig.max() <= 127
+    # reconstruction error: at most half a unit of the last limb
+    X = sum(ref_dig[l] * 256 ** l for l in range(L))
+    assert np.all(np.abs(x.astype(np.float64) - X * ref_delta[:, None].astype(np.float64)) <= 0.5 * ref_delta[:, None] * (1 + 1e-7))
+
+
+def test_activation_limbs_grouped_layout(fq):
+    from fused_int4_amd import ops
+    rng = np.random.default_rng(6)
+    T, K = 50, 256
+    x = rng.standard_normal((T, K)).astype(np.float32)
+    counts = np.array([7, 0, 33, 5], dtype=np.int32)        # 5 trailing rows uncovered
+    offs = np.array([0, 7, 7, 40], dtype=np.int32)
+    limbs, delta, rowsum = ops.act_quant(dev(x), precision="exact", tokens_per_expert=dev(counts), input_offsets=dev(offs))
+    dig, covered = decode_limbs(limbs.cpu().numpy(), 3, T, 4, K, 256, counts, offs)
+    ref_dig, ref_delta, _ = act_limbs_reference(x, 3)
+    assert covered.sum() == 45
+    assert np.array_equal(dig[:, covered], ref_dig[:, covered])
+    assert np.array_equal(delta.cpu().numpy()[covered], ref_delta[covered])
+
+
+# ------------------------------------------------------------------------------ linear: reference's own cases
+def test_golden_f2_64x128_1d(fq):
+    """tests/test_correctness.py:201-219 (atol=1e-3) through the drop-in operator name."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(fq.__file__), "dropin"))
+    import fused_quant_linear_cuda as ext
+    g = load_golden("f2_linear_64x128")
+    out = ext.forward(dev(g["x"]), dev(g["packed"]), dev(g["scales"]), dev(g["zero_points"]))
+    assert out.shape == (64,)
+    assert torch.allclose(torch.from_numpy(g["out"]), out.cpu(), atol=1e-3)
+    assert rel_fro(out.cpu().numpy(), g["out"]) < FMA_REL_FRO
+
+
+def test_golden_f3_256x512_b4(fq):
+    """tests/test_correctness.py:221-234 (atol=1e-3)."""
+    from fused_int4_amd import ops
+    g = load_golden("f3_linear_256x512_b4")
+    out = ops.linear_forward(dev(g["x"]), dev(g["packed"]), dev(g["scales"]), dev(g["zero_points"]))
+    assert out.shape == (4, 256)
+    assert torch.allclose(torch.from_numpy(g["out"]), out.cpu(), atol=1e-3)
+
+
+def test_golden_f5_4096x4096_rows(fq):
+    """tests/test_correctness.py:236-253 (atol=1e-2), the 64-row slice kept in the fixture."""
+    from fused_int4_amd import ops
+    g = load_golden("f5_linear_4096_rows64")
+    out = ops.linear_forward(dev(g["x"]), dev(g["packed"]), dev(g["scales"]), dev(g["zero_points"]))
+    assert torch.allclose(torch.from_numpy(g["out"]), out.cpu(), atol=1e-2)
+    assert np.abs(out.cpu().numpy() - g["out"]).max() < 1e-3
+
+
+def test_golden_f6_module(fq):
+    g = load_golden("f6_module_128x64")
+    lin = torch.nn.Linear(128, 64, bias=False)
+    lin.weight.data = torch.from_numpy(g["weight"])
+    ql = fq.QuantizedLinear.from_linear(lin).cuda()
+    assert sorted(ql.state_dict().keys()) == list(g["state_dict_keys"])
+    assert np.array_equal(ql.packed_weights.cpu().numpy(), g["packed_weights"])
+    o1 = ql(dev(g["x1"]))
+    o4 = ql(dev(g["x4"]))
+    assert o1.shape == (64,) and o4.shape == (4, 64)
+    assert torch.allclose(torch.from_numpy(g["out1"]), o1.cpu(), atol=1e-3)
+    assert torch.allclose(torch.from_numpy(g["out4"]), o4.cpu(), atol=1e-3)
+    assert ql.extra_repr() == str(g["extra_repr"])
+
+
+# ------------------------------------------------------------------------------ linear: every kernel path
+@pytest.mark.parametrize("B", [1, 2, 3, 4])
+@pytest.mark.parametrize("N,K", [(64, 128), (1000, 512), (11008, 4096)])
+def test_gemv_path(fq, B, N, K):
+    from fused_int4_amd import ops
+    x, p, s, z = make_problem(N, K, B, 100 + B)
+    out = ops.linear_forward(dev(x), dev(p), dev(s), dev(z)).cpu().numpy()
+    ref = C.linear_f64acc(x, p, s, z)
+    assert rel_fro(out, ref) < FMA_REL_FRO
+    assert np.allclose(out, O.reference_quantized_linear(x, p, s, z), atol=1e-2 if K > 1024 else 1e-3, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,N,K", [(5, 64, 128), (8, 96, 32), (33, 200, 96), (64, 192, 256), (100, 1000, 544),
+                                   (128, 256, 1024), (129, 193, 2048), (300, 400, 320), (512, 384, 4096)])
+@pytest.mark.parametrize("prec,tol", [("exact", EXACT_REL_FRO), ("fast", FAST_REL_FRO)])
+def test_mfma_path_shapes(fq, B, N, K, prec, tol):
+    """B > 4 with K % 32 == 0: activation pre-pass + MFMA GEMM; ragged M, N and K tails."""
+    from fused_int4_amd import ops
+    x, p, s, z = make_problem(N, K, B, B + N)
+    out = ops.linear_forward(dev(x), dev(p), dev(s), dev(z), precision=prec).cpu().numpy()
+    ref = C.linear_f64acc(x, p, s, z)
+    assert out.shape == ref.shape
+    assert rel_fro(out, ref) < tol
+    if prec == "exact":      # the reference's GPU test tolerance, at every shape
+        assert np.allclose(out, O.reference_quantized_linear(x, p, s, z), atol=1e-3 if K <= 1024 else 1e-2, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,N,K", [(1, 10, 2), (3, 17, 6), (8, 5, 34), (20, 33, 66), (6, 64, 4098)])
+def test_generic_path_odd_shapes(fq, B, N, K):
+    """K % 32 != 0 (the reference only requires even K): shape-generic fused kernel."""
+    from fused_int4_amd import ops
+    x, p, s, z = make_problem(N, K, B, 7 * B + K)
+    out = ops.linear_forward(dev(x), dev(p), dev(s), dev(z)).cpu().numpy()
+    assert rel_fro(out, C.linear_f64acc(x, p, s, z)) < FMA_REL_FRO
+
+
+def test_integer_inputs_are_bit_exact(fq):
+    """Integer-valued activations make the fixed-point conversion exact, so the MFMA path must reproduce
+    float32(scale * float32(integer dot product)) bit for bit -- the INT4 unpack, the k permutation,
+    the fragment layouts and the limb recombination all have to be right for that."""
+    from fused_int4_amd import ops
+    rng = np.random.default_rng(11)
+    B, N, K = 96, 320, 1024
+    q = rng.integers(0, 16, size=(N, K), dtype=np.uint8)
+    p = ((q[:, 1::2] << 4) | q[:, 0::2]).astype(np.uint8)
+    zp = rng.integers(0, 16, size=N).astype(np.float32)
+    sc = (rng.random(N).astype(np.float32) + 0.5) * np.float32(0.01)
+    x = rng.integers(-2000, 2001, size=(B, K)).astype(np.float32)
+    x[:, 0] = 2048.0                                        # row max = 2^11 -> delta = 2^-11 exactly divides
+    exact_int = x.astype(np.int64) @ (q.astype(np.int64) - zp.astype(np.int64)[:, None]).T      # [B,N]
+    assert np.abs(exact_int).max() < 2 ** 53
+    # the kernel's own last steps: float32 Horner of exact limb sums, * delta, * scale
+    out = ops.linear_forward(dev(x), dev(p), dev(sc), dev(zp), precision="exact").cpu().numpy()
+    ref = (exact_int.astype(np.float64) * sc.astype(np.float64)[None, :])
+    assert rel_fro(out, ref) < 3e-7
+    # values small enough to be exactly representable end to end -> bit exact
+    x2 = rng.integers(-7, 8, size=(B, K)).astype(np.float32)
+    ei = x2.astype(np.int64) @ (q.astype(np.int64) - zp.astype(np.int64)[:, None]).T
+    assert np.abs(ei).max() < 2 ** 24
+    out2 = ops.linear_forward(dev(x2), dev(p), dev(sc), dev(zp), precision="exact").cpu().numpy()
+    assert np.array_equal(out2, (ei.astype(np.float32) * sc[None, :]).astype(np.float32))
+    out3 = ops.linear_forward(dev(x2), dev(p), dev(sc), dev(zp), precision="fast").cpu().numpy()
+    assert np.array_equal(out3, out2)
+
+
+def test_non_integer_zero_points(fq):
+    """The format stores zero_points as float32; nothing forces them to be integers."""
+    from fused_int4_amd import ops
+    x, p, s, z = make_problem(128, 256, 40, 21)
+    z = (z + 0.37).astype(np.float32)
+    for B in (2, 40):
+        out = ops.linear_forward(dev(x[:B]), dev(p), dev(s), dev(z)).cpu().numpy()
+        assert rel_fro(out, C.linear_f64acc(x[:B], p, s, z)) < 5e-6
+
+
+def test_special_rows(fq):
+    from fused_int4_amd import ops
+    x, p, s, z = make_problem(64, 256, 16, 22)
+    x[0] = 0.0
+    x[1] *= 1e-20
+    x[2] *= 1e20
+    x[3, 5] = np.inf
+    x[4, 9] = np.nan
+    out = ops.linear_forward(dev(x), dev(p), dev(s), dev(z)).cpu().numpy()
+    ref = C.linear_f64acc(x[:3], p, s, z)
+    assert (out[0] == 0).all()
+    assert rel_fro(out[1], ref[1]) < EXACT_REL_FRO and rel_fro(out[2], ref[2]) < EXACT_REL_FRO
+    assert np.isnan(out[3]).all() and np.isnan(out[4]).all()      # documented: a non-finite activation poisons its row
+    assert np.isfinite(out[5:]).all()
+
+
+# ------------------------------------------------------------------------------ error behaviour (csrc/quantized_linear_kernel.cu:311-335)
+def test_linear_errors(fq):
+    from fused_int4_amd import ops
+    x, p, s, z = make_problem(64, 128, 2, 1)
+    X, P, S, Z = dev(x), dev(p), dev(s), dev(z)
+    with pytest.raises(RuntimeError, match="input must be a CUDA tensor"):
+        ops.linear_forward(torch.from_numpy(x), P, S, Z)
+    with pytest.raises(RuntimeError, match="packed_weights must be a CUDA tensor"):
+        ops.linear_forward(X, torch.from_numpy(p), S, Z)
+    with pytest.raises(RuntimeError, match="input must be contiguous"):
+        ops.linear_forward(dev(np.zeros((128, 2), np.float32)).t(), P, S, Z)
+    with pytest.raises(RuntimeError, match="input must be float32"):
+        ops.linear_forward(X.double(), P, S, Z)
+    with pytest.raises(RuntimeError, match="packed_weights must be uint8"):
+        ops.linear_forward(X, P.to(torch.int32), S, Z)
+    with pytest.raises(RuntimeError, match="scales must be float32"):
+        ops.linear_forward(X, P, S.double(), Z)
+    with pytest.raises(RuntimeError, match="packed_weights dim 1 must be input_dim / 2"):
+        ops.linear_forward(X[:, :64].contiguous(), P, S, Z)
+    with pytest.raises(RuntimeError, match="output_dim elements"):
+        ops.linear_forward(X, P, S[:10], Z)
+    with pytest.raises(ValueError):
+        ops.linear_forward(X, P, S, Z, precision="bf16")
+    # empty batch
+    assert ops.linear_forward(X[:0], P, S, Z).shape == (0, 64)
+
+
+# ------------------------------------------------------------------------------ MoE
+def make_moe(E, N, K, counts, seed, gap_rows=0, wscale=0.02):
+    rng = np.random.default_rng(seed)
+    P, S, Z = [], [], []
+    for _ in range(E):
+        p, s, z = O.quantize_weights((rng.standard_normal((N, K)) * wscale).astype(np.float32))
+        P.append(p); S.append(s); Z.append(z)
+    counts = np.asarray(counts, dtype=np.int32)
+    offs = (np.cumsum(counts) - counts).astype(np.int32)
+    T = int(counts.sum()) + gap_rows
+    x = rng.standard_normal((T, K)).astype(np.float32)
+    return np.stack(P), np.stack(S), np.stack(Z), x, counts, offs
+
+
+@pytest.mark.parametrize("E,N,K,counts,gap", [
+    (4, 256, 128, [40, 0, 33, 20], 3),
+    (8, 384, 512, [128] * 8, 0),
+    (8, 200, 256, [300, 1, 0, 17, 129, 64, 0, 5], 11),
+    (3, 64, 96, [5, 6, 7], 0),                               # K % 256 != 0
+    (2, 130, 34, [9, 4], 2),                                 # K % 32 != 0 -> generic grouped kernel
+    (16, 192, 256, [0] * 15 + [50], 0),
+])
+@pytest.mark.parametrize("prec,tol", [("exact", EXACT_REL_FRO), ("fast", FAST_REL_FRO)])
+def test_moe_grouped_parity(fq, E, N, K, counts, gap, prec, tol):
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(fq.__file__), "dropin"))
+    import moe_int4_cuda as ext
+    P, S, Z, x, cnt, offs = make_moe(E, N, K, counts, sum(counts) + E, gap_rows=gap)
+    T = x.shape[0]
+    expert_ids = torch.zeros(T, dtype=torch.int32).cuda()    # accepted, ignored (reference :98)
+    if prec == "exact":
+        out = ext.forward(dev(P), dev(S), dev(Z), dev(x), expert_ids, dev(cnt), dev(offs)).cpu().numpy()
+    else:
+        from fused_int4_amd import ops
+        out = ops.moe_forward(dev(P), dev(S), dev(Z), dev(x), None, dev(cnt), dev(offs), precision="fast").cpu().numpy()
+    ref = C.moe_grouped(P, S, Z, x, cnt, offs)
+    assert out.shape == (T, N)
+    assert rel_fro(out, ref) < (tol if K % 32 == 0 else FMA_REL_FRO)
+    covered = np.zeros(T, bool)
+    for c, o in zip(cnt, offs):
+        covered[o:o + c] = True
+    assert (out[~covered] == 0).all()                        # torch::zeros semantics (reference :109)
+
+
+def test_moe_equals_per_expert_linear_bitwise(fq):
+    """Integer-exact accumulation: the grouped launch and E separate linear launches (other tile
+    shapes, other row offsets) must agree bit for bit."""
+    from fused_int4_amd import ops
+    P, S, Z, x, cnt, offs = make_moe(4, 320, 512, [70, 130, 8, 200], 77)
+    out = ops.moe_forward(dev(P), dev(S), dev(Z), dev(x), None, dev(cnt), dev(offs)).cpu().numpy()
+    for e in range(4):
+        o, c = int(offs[e]), int(cnt[e])
+        single = ops.linear_forward(dev(x[o:o + c]), dev(P[e]), dev(S[e]), dev(Z[e])).cpu().numpy()
+        assert np.array_equal(single, out[o:o + c]), e
+
+
+def test_moe_golden_f8_quantized_moe(fq):
+    """QuantizedMoE (benchmark/moe_grouped_gemm/moe_int4_module.py) vectors from the reference."""
+    g = load_golden("f8_quantized_moe")
+    ws = [torch.from_numpy(w) for w in g["weights"]]
+    moe = fq.QuantizedMoE.from_fp16_weights(ws).cuda()
+    for e in range(4):
+        assert np.array_equal(moe.experts[e].packed_weights.cpu().numpy(), g[f"packed{e}"])
+    assert moe.total_memory_bytes == int(g["total_memory_bytes"])
+    assert sorted(moe.state_dict().keys()) == list(g["state_dict_keys"])
+    m = g["m_sizes"]
+    offs = np.concatenate([[0], np.cumsum(m)[:-1]])
+    xin = [dev(g["x32"][o:o + c]) for o, c in zip(offs, m)]
+    outs = moe(xin)
+    assert outs[3].shape == (0, 256) and outs[3].dtype == torch.float16      # reference quirk :65-68
+    got = torch.cat([o for o in outs if o.shape[0]]).cpu().numpy()
+    assert np.allclose(got, g["out32"], atol=1e-5)
+    outs16 = moe([t.half() for t in xin])
+    assert outs16[0].dtype == torch.float16
+    got16 = torch.cat([o for o in outs16 if o.shape[0]]).float().cpu().numpy()
+    assert np.allclose(got16, g["out16"].astype(np.float32), atol=2e-3, rtol=2e-3)
+
+
+def test_moeint4_module_per_tensor(fq):
+    """MoEINT4 (python/moe_int4_module.py:83-146): per-tensor quantiser + grouped forward."""
+    g = load_golden("f7_moe_per_tensor")
+    # quantise on the CPU (where the golden vectors were made: GPU float division may differ by 1 ulp),
+    # then move the module -- the usual construction path
+    mod = fq.MoEINT4.from_weights([torch.from_numpy(w) for w in g["weights"]]).cuda()
+    gpu_q = fq.quantize_weights_moe([torch.from_numpy(w).cuda() for w in g["weights"]])
+    assert np.allclose(gpu_q[1].cpu().numpy(), g["scales"], rtol=1e-6)
+    assert np.array_equal(mod.packed_weights.cpu().numpy(), g["packed"])
+    assert np.array_equal(mod.scales.cpu().numpy(), g["scales"])
+    assert np.array_equal(mod.zero_points.cpu().numpy(), g["zero_points"])
+    assert sorted(mod.state_dict().keys()) == list(g["state_dict_keys"])
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((24, 64)).astype(np.float32)
+    cnt = np.array([10, 14], np.int32); offs = np.array([0, 10], np.int32)
+    out = mod(dev(x), torch.zeros(24, dtype=torch.int32).cuda(), dev(cnt), dev(offs)).cpu().numpy()
+    ref = C.moe_grouped(g["packed"], g["scales"], g["zero_points"], x, cnt, offs)
+    assert rel_fro(out, ref) < EXACT_REL_FRO
+
+
+def test_moe_clipping_of_bad_ranges(fq):
+    """Offsets / counts that leave [0, T] are clipped on the device; nothing faults."""
+    from fused_int4_amd import ops
+    P, S, Z, x, cnt, offs = make_moe(3, 128, 256, [10, 10, 10], 5)
+    cnt2 = np.array([10, 10, 999], np.int32)
+    offs2 = np.array([0, 10, 20], np.int32)
+    out = ops.moe_forward(dev(P), dev(S), dev(Z), dev(x), None, dev(cnt2), dev(offs2)).cpu().numpy()
+    ref = C.moe_grouped(P, S, Z, x, cnt, offs)
+    assert rel_fro(out, ref) < EXACT_REL_FRO
+
+
+# ------------------------------------------------------------------------------ BASELINE.json sizes: size-independent properties
+def test_full_size_moe_properties(fq):
+    """configs[2]: 8 experts 4096 -> 11008, 1024 routed rows.  Checked by (a) the oracle on a row sample,
+    (b) linearity in the activations (exact for power-of-two scaling), (c) grouped == per-expert
+    bit for bit, (d) column-checksum against the dequantised-weight checksum."""
+    from fused_int4_amd import ops
+    E, K, N = 8, 4096, 11008
+    g = torch.Generator(device="cuda").manual_seed(9)
+    P, S, Z = [], [], []
+    for _ in range(E):
+        p, s, z = fq.quantize_weights(torch.randn(N, K, device="cuda", generator=g) * 0.02)
+        P.append(p); S.append(s); Z.append(z)
+    P, S, Z = torch.stack(P), torch.stack(S), torch.stack(Z)
+    cnt = torch.tensor([128] * 8, dtype=torch.int32, device="cuda")
+    offs = torch.cumsum(cnt, 0).to(torch.int32) - cnt
+    x = torch.randn(1024, K, device="cuda", generator=g)
+    out = ops.moe_forward(P, S, Z, x, None, cnt, offs)
+    # (a) oracle on sampled rows (float64 accumulation on the CPU)
+    rows = [0, 127, 128, 500, 1023]
+    Pn, Sn, Zn = P.cpu().numpy(), S.cpu().numpy(), Z.cpu().numpy()
+    for r in rows:
+        e = r // 128
+        ref = C.linear_f64acc(x[r].cpu().numpy(), Pn[e], Sn[e], Zn[e])
+        assert rel_fro(out[r].cpu().numpy(), ref) < EXACT_REL_FRO, r
+        assert np.allclose(out[r].cpu().numpy(), ref, atol=1e-3)
+    # (b) scaling the activations by 2^k scales the outputs exactly
+    out4 = ops.moe_forward(P, S, Z, x * 4.0, None, cnt, offs)
+    assert torch.equal(out4, out * 4.0)
+    # (c) grouped launch == single-expert launch on the same rows, bit for bit
+    single = ops.linear_forward(x[256:384].contiguous(), P[2], S[2], Z[2])
+    assert torch.equal(single, out[256:384])
+    # (d) checksum of checksums: sum_n out[t,n] == x[t] . (sum_n W[n,:])
+    wsum = fq.dequantize_weights(P[5], S[5], Z[5]).double().sum(0)
+    lhs = out[640:768].double().sum(1)
+    rhs = x[640:768].double() @ wsum
+    assert torch.allclose(lhs, rhs, rtol=1e-5, atol=1e-3)
+
+
+def test_full_size_linear_b512(fq):
+    """configs[1]: QuantizedLinear 4096 -> 11008, batch 512."""
+    from fused_int4_amd import ops
+    K, N = 4096, 11008
+    g = torch.Generator(device="cuda").manual_seed(10)
+    p, s, z = fq.quantize_weights(torch.randn(N, K, device="cuda", generator=g) * 0.02)
+    x = torch.randn(512, K, device="cuda", generator=g)
+    out = ops.linear_forward(x, p, s, z)
+    pn, sn, zn = p.cpu().numpy(), s.cpu().numpy(), z.cpu().numpy()
+    for r in (0, 255, 511):
+        ref = C.linear_f64acc(x[r].cpu().numpy(), pn, sn, zn)
+        assert rel_fro(out[r].cpu().numpy(), ref) < EXACT_REL_FRO
+    # batch-1 GEMV kernel (float32 FMA) agrees with the MFMA kernel to float32 noise
+    o1 = ops.linear_forward(x[7], p, s, z)
+    assert rel_fro(o1.cpu().numpy(), out[7].cpu().numpy()) < 5e-6
+    # fast mode stays inside the north-star bound (<= 1e-3 relative) by a wide margin
+    of = ops.linear_forward(x, p, s, z, precision="fast")
+    assert rel_fro(of[:16].cpu().numpy(), out[:16].cpu().numpy()) < FAST_REL_FRO
