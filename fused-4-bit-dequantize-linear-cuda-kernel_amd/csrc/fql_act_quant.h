@@ -17,9 +17,8 @@
 //   is (0,2,4,6,1,3,5,7), the order the in-register nibble unpack (unpack8) produces.
 //   Columns K..Kp-1 are zero.
 //
-// HBM-bound: reads T*K*4 bytes (second pass hits L2), writes L*T*Kp bytes.  One 256-thread
-// workgroup per row.  For the MoE entry point the same launch also zero-fills the rows of `out`
-// that no expert covers (reference semantics: torch::zeros, csrc/moe_int4_kernel.cu:109).
+// HBM-bound: reads T*K*4 bytes twice (the second read hits L2 / Infinity Cache), writes L*T*Kp bytes
+// in contiguous 8 KiB blocks.  Two launches: per-row scale, then the tiled conversion.
 #pragma once
 #include "fql_common.h"
 #include <math.h>
@@ -41,44 +40,27 @@ __device__ __forceinline__ int act_exponent(float m)
     return e;
 }
 
-// byte offset of the 8-byte group holding k0..k0+7 (k0 % 8 == 0) of padded row p, limb l
-__device__ __forceinline__ size_t limb_offset(int l, int k0, int p, int KB, int MBT)
-{
-    const int kb = k0 >> 8, kin = k0 & 255;
-    const int c = kin >> 5, v = c >> 1, g = c & 1, b = (kin >> 4) & 1;
-    const int ks = 2 * v + b;
-    const size_t blk = ((size_t)l * KB + kb) * MBT + (p >> 5);
-    return ((blk * 8 + ks) * 64 + (g * 32 + (p & 31))) * 16 + (kin & 8);
-}
-
+// ---- kernel 1: per-row scale.  One 256-thread workgroup per row (all loads independent and in
+//      flight together): delta[t] = 2^e (NaN for a non-finite row) and the per-limb digit sums rowsum[l][t];
+//      for the MoE entry point also zero-fills the rows of `out` that no expert covers (reference
+//      semantics: torch::zeros, csrc/moe_int4_kernel.cu:109).
 template <int L>
-__global__ __launch_bounds__(256) void act_quant_kernel(
-    const float *__restrict__ x, int8_t *__restrict__ limbs, float *__restrict__ delta,
-    int32_t *__restrict__ rowsum, int T, int K, int Kp, int MBT,
-    float *__restrict__ out, int N, const int32_t *__restrict__ tpe,
-    const int32_t *__restrict__ offs, int E)
+__global__ __launch_bounds__(256) void act_scale_kernel(
+    const float *__restrict__ x, float *__restrict__ delta, int32_t *__restrict__ rowsum, int T, int K,
+    float *__restrict__ out, int N, const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs, int E)
 {
     __shared__ float s_red[4];
     __shared__ int s_bad[4];
-    __shared__ int s_sum[4 * L];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int t = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-
-    int p = t;                            // padded row of t in the limb workspace
-    if (tpe != nullptr) {                 // MoE: find the covering expert and its padded base
+    if (tpe != nullptr) {
         bool covered = false;
-        int pbase = 0;
-        for (int e = 0; e < E; ++e) {
-            int lo, cnt;
-            expert_range(tpe, offs, e, T, lo, cnt);
-            if (!covered && t >= lo && t < lo + cnt) {
-                covered = true;
-                p = pbase + (t - lo);
-            }
-            pbase += (cnt + FQL_MB - 1) / FQL_MB * FQL_MB;
+        int cp = 0, ct = 0;
+        for (int base = 0; base < E; base += 64) {
+            const ExpertLane xl = expert_chunk(tpe, offs, E, T, FQL_MB, base, lane, cp, ct);
+            covered |= __ballot(t >= xl.lo && t < xl.lo + xl.cnt) != 0ull;
         }
-        if (!covered) {                   // rows covered by no expert are zeroed, not computed
+        if (!covered) {
             if (out != nullptr) {
                 float *orow = out + (size_t)t * N;
                 for (int i = tid; i < N; i += 256) orow[i] = 0.0f;
@@ -86,27 +68,32 @@ __global__ __launch_bounds__(256) void act_quant_kernel(
             return;
         }
     }
-
     const float *xr = x + (size_t)t * K;
     const bool vec_ok = ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-
-    // pass 1: row max magnitude (+ non-finite detection)
     float m = 0.0f;
     int bad = 0;
     if (vec_ok) {
         const v4f *xv = reinterpret_cast<const v4f *>(xr);
-        for (int i = tid; i < (K >> 2); i += 256) {
-            v4f v = xv[i];
+        const int nv = K >> 2;
+        for (int i0 = 0; i0 < nv; i0 += 1024) {               // 4 independent 16-byte loads per thread per trip
+            v4f v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float a = fabsf(v[j]);
-                bad |= !(a <= 3.402823466e+38f);
-                m = fmaxf(m, a);
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256 + tid;
+                v[u] = (i < nv) ? xv[i] : v4f{0.f, 0.f, 0.f, 0.f};
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = fabsf(v[u][j]);
+                    bad |= !(a <= 3.402823466e+38f);
+                    m = fmaxf(m, a);
+                }
         }
     } else {
         for (int i = tid; i < K; i += 256) {
-            float a = fabsf(xr[i]);
+            const float a = fabsf(xr[i]);
             bad |= !(a <= 3.402823466e+38f);
             m = fmaxf(m, a);
         }
@@ -117,54 +104,46 @@ __global__ __launch_bounds__(256) void act_quant_kernel(
     __syncthreads();
     m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
     bad = s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3];
-    if (bad) m = 0.0f;                    // non-finite row: limbs 0, delta NaN -> the row's outputs are NaN
+    const int e = act_exponent<L>(bad ? 0.0f : m);
+    const float inv = bad ? 0.0f : ldexpf(1.0f, -e);
 
-    const int e = act_exponent<L>(m);
-    const float inv = ldexpf(1.0f, -e);
-    const int KB = Kp / FQL_KB;
-
-    // pass 2: quantise 8 consecutive k per thread, write one permuted 8-byte group per limb
+    // second pass over the row (L1 / L2 hits): the per-limb digit sums, so kernel 2 needs no atomics
     int sums[L];
 #pragma unroll
     for (int l = 0; l < L; ++l) sums[l] = 0;
-
-    const int G = Kp >> 3;
-    for (int gi = tid; gi < G; gi += 256) {
-        const int k0 = gi << 3;
-        float v[8];
-        if (vec_ok && k0 + 8 <= K) {
-            v4f a = *reinterpret_cast<const v4f *>(xr + k0);
-            v4f b = *reinterpret_cast<const v4f *>(xr + k0 + 4);
-            v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
-            v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-        } else {
+    auto add = [&](float v) {
+        int X = (int)rintf(v * inv);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (k0 + j < K) ? xr[k0 + j] : 0.0f;
+        for (int l = 0; l < L; ++l) {
+            int d;
+            if (l == L - 1) d = X;
+            else { d = ((X + 128) & 255) - 128; X = (X - d) >> 8; }
+            sums[l] += d;
         }
-        uint32_t w[L][2];
+    };
+    if (vec_ok) {
+        const v4f *xv = reinterpret_cast<const v4f *>(xr);
+        const int nv = K >> 2;
+        for (int i0 = 0; i0 < nv; i0 += 1024) {
+            v4f v[4];
 #pragma unroll
-        for (int l = 0; l < L; ++l) w[l][0] = w[l][1] = 0u;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            int X = bad ? 0 : (int)rintf(v[j] * inv);
-            const int pos = (j >> 1) + ((j & 1) << 2);          // (0,2,4,6,1,3,5,7) -> 0..7
-#pragma unroll
-            for (int l = 0; l < L; ++l) {
-                int d;
-                if (l == L - 1) d = X;                           // top limb: remaining value, in range by construction
-                else { d = ((X + 128) & 255) - 128; X = (X - d) >> 8; }
-                sums[l] += d;
-                w[l][pos >> 2] |= (uint32_t)(d & 255) << ((pos & 3) * 8);
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256 + tid;
+                v[u] = (i < nv) ? xv[i] : v4f{0.f, 0.f, 0.f, 0.f};
             }
-        }
 #pragma unroll
-        for (int l = 0; l < L; ++l)
-            *reinterpret_cast<uint2 *>(limbs + limb_offset(l, k0, p, KB, MBT)) = make_uint2(w[l][0], w[l][1]);
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) add(v[u][j]);
+        }
+    } else {
+        for (int i = tid; i < K; i += 256) add(xr[i]);
     }
+    __shared__ int s_sum[4 * L];
 #pragma unroll
     for (int l = 0; l < L; ++l) {
-        int s = wave_sum_i(sums[l]);
-        if (lane == 0) s_sum[wave * L + l] = s;
+        const int sv = wave_sum_i(sums[l]);
+        if (lane == 0) s_sum[wave * L + l] = sv;
     }
     __syncthreads();
     if (tid == 0) {
@@ -172,5 +151,105 @@ __global__ __launch_bounds__(256) void act_quant_kernel(
 #pragma unroll
         for (int l = 0; l < L; ++l)
             rowsum[(size_t)l * T + t] = s_sum[l] + s_sum[L + l] + s_sum[2 * L + l] + s_sum[3 * L + l];
+    }
+}
+
+// ---- kernel 2: one workgroup per (32-row block mb, 256-k block kb).  Coalesced float4 reads of the
+//      32 x 256 tile (all 8 loads of a thread issued before any is used), quantise to L limbs, scatter the
+//      bytes into the fragment image in LDS, then stream the L contiguous 8 KiB fragment blocks out with
+//      16-byte stores.
+template <int L>
+__global__ __launch_bounds__(256) void act_limbs_kernel(
+    const float *__restrict__ x, const float *__restrict__ delta, int8_t *__restrict__ limbs,
+    int T, int K, int KB, int MBT,
+    const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs, int E)
+{
+    __shared__ __attribute__((aligned(16))) char img[L * 8192];
+    __shared__ int s_tok[FQL_MB];
+    const int mb = blockIdx.x, kb = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int gi = tid & 31;                      // 8-group inside the 256-k block
+    const bool vec_ok = ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+
+    if (tid < 64) {                               // token row of each of the block's 32 padded rows (-1: padding)
+        if (tpe == nullptr) {
+            if (tid < FQL_MB) s_tok[tid] = (mb * FQL_MB + tid < T) ? mb * FQL_MB + tid : -1;
+        } else {
+            if (tid < FQL_MB) s_tok[tid] = -1;
+            int cp = 0, ct = 0;
+            for (int base = 0; base < E; base += 64) {
+                const ExpertLane xl = expert_chunk(tpe, offs, E, T, FQL_MB, base, tid, cp, ct);
+                for (int r = 0; r < FQL_MB; ++r) {
+                    const int p = mb * FQL_MB + r;
+                    const unsigned long long hit = __ballot(p >= xl.pad_excl && p - xl.pad_excl < xl.cnt);
+                    if (hit) {
+                        const int src = __ffsll((long long)hit) - 1;
+                        const int tk = __shfl(xl.lo, src, 64) + p - __shfl(xl.pad_excl, src, 64);
+                        if (tid == 0 && s_tok[r] < 0) s_tok[r] = tk;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int k0 = kb * FQL_KB + gi * 8;
+    int tok[4];
+    float inv[4];
+    v4f va[4], vb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        tok[j] = s_tok[(tid >> 5) + 8 * j];
+        va[j] = vb[j] = v4f{0.f, 0.f, 0.f, 0.f};
+        inv[j] = 0.0f;
+        if (tok[j] >= 0) {
+            const float *xr = x + (size_t)tok[j] * K;
+            if (vec_ok && k0 + 8 <= K) {
+                va[j] = *reinterpret_cast<const v4f *>(xr + k0);
+                vb[j] = *reinterpret_cast<const v4f *>(xr + k0 + 4);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    va[j][i] = (k0 + i < K) ? xr[k0 + i] : 0.0f;
+                    vb[j][i] = (k0 + 4 + i < K) ? xr[k0 + 4 + i] : 0.0f;
+                }
+            }
+            const float d = delta[tok[j]];
+            inv[j] = (d == d) ? 1.0f / d : 0.0f;  // delta is a power of two: exact reciprocal; NaN row -> limbs 0
+        }
+    }
+    // fragment position of this 8-group: chunk c = gi / 4 -> (v = c >> 1, g = c & 1), half b, byte 8*(gi & 1)
+    const int c = gi >> 2, b = (gi >> 1) & 1;
+    const int ks = 2 * (c >> 1) + b, g = c & 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (tid >> 5) + 8 * j;
+        const float v[8] = {va[j][0], va[j][1], va[j][2], va[j][3], vb[j][0], vb[j][1], vb[j][2], vb[j][3]};
+        uint32_t w[L][2];
+#pragma unroll
+        for (int l = 0; l < L; ++l) w[l][0] = w[l][1] = 0u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int X = (int)rintf(v[i] * inv[j]);
+            const int pos = (i >> 1) + ((i & 1) << 2);           // (0,2,4,6,1,3,5,7) -> 0..7
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                int d;
+                if (l == L - 1) d = X;                            // top limb: remaining value, in range by construction
+                else { d = ((X + 128) & 255) - 128; X = (X - d) >> 8; }
+                w[l][pos >> 2] |= (uint32_t)(d & 255) << ((pos & 3) * 8);
+            }
+        }
+        const int off = ((ks * 64) + g * 32 + r) * 16 + ((gi & 1) << 3);
+#pragma unroll
+        for (int l = 0; l < L; ++l) *reinterpret_cast<uint2 *>(img + l * 8192 + off) = make_uint2(w[l][0], w[l][1]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        int8_t *dst = limbs + (((size_t)l * KB + kb) * MBT + mb) * 8192;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<v4i *>(dst + (i * 256 + tid) * 16) = *reinterpret_cast<const v4i *>(img + l * 8192 + (i * 256 + tid) * 16);
     }
 }

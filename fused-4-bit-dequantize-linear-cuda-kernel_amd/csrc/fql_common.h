@@ -63,3 +63,42 @@ __device__ __forceinline__ void expert_range(const int32_t *tpe, const int32_t *
     lo = (int)a;
     cnt = b > a ? (int)(b - a) : 0;
 }
+
+// ---- expert table by one wavefront: lane i owns expert base + i.  All E (lo, cnt) pairs are fetched with
+//      ONE vector load per array (a sequential scalar scan costs ~2 dependent L2 round trips per expert at
+//      the head of every workgroup) and the running sums come from a 6-step shuffle scan.
+struct ExpertLane {
+    int lo, cnt;        // clipped row range of this lane's expert (cnt = 0 for lanes past E)
+    int pad_excl;       // padded rows (multiples of FQL_MB) of all earlier experts
+    int tile_excl;      // m-tiles of all earlier experts (tile height bm)
+    int tiles;          // m-tiles of this expert
+};
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int n = __shfl_up(v, o, 64);
+        if (lane >= o) v += n;
+    }
+    return v;
+}
+
+// Processes experts [base, base + 64); carry_pad / carry_tile are the totals of the experts before `base`
+// and are advanced to include this chunk.
+__device__ __forceinline__ ExpertLane expert_chunk(const int32_t *tpe, const int32_t *offs, int E, int T, int bm,
+                                                   int base, int lane, int &carry_pad, int &carry_tile)
+{
+    ExpertLane r;
+    r.lo = 0; r.cnt = 0;
+    if (base + lane < E) expert_range(tpe, offs, base + lane, T, r.lo, r.cnt);
+    const int pad = (r.cnt + FQL_MB - 1) / FQL_MB * FQL_MB;
+    r.tiles = (r.cnt + bm - 1) / bm;
+    const int pad_incl = wave_incl_scan(pad, lane);
+    const int tile_incl = wave_incl_scan(r.tiles, lane);
+    r.pad_excl = carry_pad + pad_incl - pad;
+    r.tile_excl = carry_tile + tile_incl - r.tiles;
+    carry_pad += __shfl(pad_incl, 63, 64);
+    carry_tile += __shfl(tile_incl, 63, 64);
+    return r;
+}

@@ -66,48 +66,55 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_kernel(
     //      sized for the worst case and surplus workgroups (the tail of the grid) exit at once.  Logical
     //      tile ids are m-tile major and dealt to XCDs in contiguous ranges, so the workgroups of one
     //      XCD share an expert's activation panel in that XCD's L2 while each weight byte streams once.
-    int m_tiles = m_slots;
-    if (tpe != nullptr) {
-        m_tiles = 0;
-        for (int i = 0; i < E; ++i) {
-            int lo, cnt;
-            expert_range(tpe, offs, i, T, lo, cnt);
-            m_tiles += (cnt + C::BM - 1) / C::BM;
-        }
-        if (m_tiles > m_slots) m_tiles = m_slots;        // overlapping ranges: stay inside the grid
-    }
-    const int n_real = m_tiles * n_tiles;
-    if ((int)blockIdx.x >= n_real) return;
-    const int tile = xcd_remap(blockIdx.x, n_real);
-    const int ms = tile / n_tiles;
-    const int nt = tile - ms * n_tiles;
-
-    int e = 0, row0 = 0, rows_valid = 0, prow0 = 0;
+    const int lane0 = threadIdx.x & 63;
+    int e = 0, row0 = 0, rows_valid = 0, prow0 = 0, nt = 0;
     if (tpe == nullptr) {                                   // linear: one group covering all T rows
+        const int n_real = m_slots * n_tiles;
+        if ((int)blockIdx.x >= n_real) return;
+        const int tile = xcd_remap(blockIdx.x, n_real);
+        const int ms = tile / n_tiles;
+        nt = tile - ms * n_tiles;
         row0 = prow0 = ms * C::BM;
         rows_valid = T - row0;
     } else {                                                // MoE: offsets/counts read on the device
-        int run = 0, pbase = 0;
+        // One vector load per 64 experts (every wave does it redundantly; nothing is shared).  With
+        // E <= 64 a single chunk gives both the total m-tile count and the owner of this m-tile.
+        int cp = 0, ct = 0;
+        const ExpertLane x0 = expert_chunk(tpe, offs, E, T, C::BM, 0, lane0, cp, ct);
+        for (int base = 64; base < E; base += 64) (void)expert_chunk(tpe, offs, E, T, C::BM, base, lane0, cp, ct);
+        const int m_tiles = ct < m_slots ? ct : m_slots;     // overlapping ranges: stay inside the grid
+        const int n_real = m_tiles * n_tiles;
+        if ((int)blockIdx.x >= n_real) return;
+        const int tile = xcd_remap(blockIdx.x, n_real);
+        const int ms = tile / n_tiles;
+        nt = tile - ms * n_tiles;
+        cp = 0; ct = 0;
         bool found = false;
-        for (int i = 0; i < E; ++i) {
-            int lo, cnt;
-            expert_range(tpe, offs, i, T, lo, cnt);
-            const int tiles = (cnt + C::BM - 1) / C::BM;
-            if (!found && ms < run + tiles) {
+        for (int base = 0; base < E && !found; base += 64) {
+            ExpertLane x = x0;
+            if (base == 0) { cp = __shfl(x0.pad_excl + (x0.cnt + FQL_MB - 1) / FQL_MB * FQL_MB, 63, 64); ct = __shfl(x0.tile_excl + x0.tiles, 63, 64); }
+            else x = expert_chunk(tpe, offs, E, T, C::BM, base, lane0, cp, ct);
+            const unsigned long long hit = __ballot(ms >= x.tile_excl && ms < x.tile_excl + x.tiles);
+            if (hit) {
+                const int src = __ffsll((long long)hit) - 1;
+                const int lo = __shfl(x.lo, src, 64), cnt = __shfl(x.cnt, src, 64);
+                const int te = __shfl(x.tile_excl, src, 64), pe = __shfl(x.pad_excl, src, 64);
+                e = base + src;
+                row0 = lo + (ms - te) * C::BM;
+                prow0 = pe + (ms - te) * C::BM;
+                rows_valid = cnt - (ms - te) * C::BM;
                 found = true;
-                e = i;
-                row0 = lo + (ms - run) * C::BM;
-                prow0 = pbase + (ms - run) * C::BM;
-                rows_valid = cnt - (ms - run) * C::BM;
             }
-            run += tiles;
-            pbase += (cnt + FQL_MB - 1) / FQL_MB * FQL_MB;
         }
         if (!found) return;
     }
     if (rows_valid <= 0) return;
     if (rows_valid > C::BM) rows_valid = C::BM;
     const int n0 = nt * C::BN;
+    e = __builtin_amdgcn_readfirstlane(e);
+    row0 = __builtin_amdgcn_readfirstlane(row0);
+    prow0 = __builtin_amdgcn_readfirstlane(prow0);
+    rows_valid = __builtin_amdgcn_readfirstlane(rows_valid);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;

@@ -76,8 +76,13 @@ template <int L>
 int launch_act_quant(const float *x, const Workspace &w, int T, int K, int Kp, int MBT, float *out, int N,
                      const int32_t *tpe, const int32_t *offs, int E, hipStream_t st)
 {
-    hipLaunchKernelGGL((act_quant_kernel<L>), dim3(T), dim3(256), 0, st, x, w.limbs, w.delta, w.rowsum, T,
-                       K, Kp, MBT, out, N, tpe, offs, E);
+    hipLaunchKernelGGL((act_scale_kernel<L>), dim3(T), dim3(256), 0, st, x, w.delta, w.rowsum, T, K, out, N,
+                       tpe, offs, E);
+    if (hipGetLastError() != hipSuccess) return FQL_ERR_LAUNCH;
+    // 32-row blocks that can hold real rows: every expert's rows rounded up to 32
+    const int mblocks = (tpe == nullptr) ? (T + FQL_MB - 1) / FQL_MB : (T + FQL_MB * E) / FQL_MB;
+    hipLaunchKernelGGL((act_limbs_kernel<L>), dim3(mblocks, Kp / FQL_KB), dim3(256), 0, st, x, w.delta, w.limbs,
+                       T, K, Kp / FQL_KB, MBT, tpe, offs, E);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
