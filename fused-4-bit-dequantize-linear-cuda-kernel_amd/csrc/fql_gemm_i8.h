@@ -26,31 +26,28 @@
 #pragma once
 #include "fql_common.h"
 
-template <int L, int WM, int WN, int NF>
+template <int L, int WM, int WN, int NF, int DEPTH>
 struct GemmCfg {
     static constexpr int NW = WM * WN;
     static constexpr int THREADS = 64 * NW;
     static constexpr int BM = FQL_MB * WM;
     static constexpr int BN = 32 * NF * WN;
     static constexpr int KS = FQL_KB / 32;                   // MFMA k-steps per weight stage (8)
-    static constexpr int D = 4;                              // A prefetch depth in k-steps (register ring)
+    static constexpr int D = DEPTH;                          // A prefetch depth in k-steps (register ring)
     static constexpr int B_STAGE = BN * (FQL_KB / 2);        // bytes of packed weights per stage
     static constexpr int LDS_BYTES = 2 * B_STAGE;
     static constexpr int CPWB = BN / 8 / NW;                 // 1 KiB weight pieces per wave per stage
-    static_assert(NW == 8, "8 waves per workgroup");
+    static_assert(NW == 8 || NW == 4, "8 waves (two per SIMD) or 4 waves (one per SIMD, 512-register budget)");
     static_assert(KS % D == 0, "ring depth must divide the steps per stage");
-    static_assert(BN % 64 == 0, "weight pieces must divide evenly over the waves");
+    static_assert((BN / 8) % NW == 0, "weight pieces must divide evenly over the waves");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 __device__ __forceinline__ void wait_lgkmcnt0() { __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14)); }
 
-#if defined(FQL_STAMP)
-__device__ unsigned long long fql_stamps[64];        // diagnostic build only
-#endif
 
-template <int L, int WM, int WN, int NF>
-__global__ __launch_bounds__(512, 2) void gemm_i8_kernel(
+template <int L, int WM, int WN, int NF, int DEPTH>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_i8_kernel(
     const int8_t *__restrict__ limbs, const float *__restrict__ delta,
     const int32_t *__restrict__ rowsum, const uint8_t *__restrict__ packed,
     const float *__restrict__ scales, const float *__restrict__ zps, float *__restrict__ out,
@@ -58,42 +55,40 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_kernel(
     int E, int T, int K, int Kp, int MBT, int N, int n_tiles, int m_slots)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub
-    using C = GemmCfg<L, WM, WN, NF>;
+    using C = GemmCfg<L, WM, WN, NF, DEPTH>;
     constexpr int KS = C::KS, D = C::D;
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
-    // ---- which tile.  Real m-tiles are counted on the device (expert counts live there); the grid is
-    //      sized for the worst case and surplus workgroups (the tail of the grid) exit at once.  Logical
-    //      tile ids are m-tile major and dealt to XCDs in contiguous ranges, so the workgroups of one
-    //      XCD share an expert's activation panel in that XCD's L2 while each weight byte streams once.
+    // ---- tiles.  Real m-tiles are counted on the device (expert counts live there).  The launch is
+    //      PERSISTENT: one workgroup per CU walks virtual block ids vb = blockIdx.x, +gridDim.x, ...; the
+    //      16-byte stores of one tile's epilogue drain while the next tile's loads and MFMAs start.
+    //      Logical tile ids are m-tile major and dealt to XCDs in contiguous ranges (vb % 8 = the XCD
+    //      group of the workgroup, for every vb it visits), so the workgroups of one XCD share an
+    //      expert's activation panel in that XCD's L2 while each weight byte streams once.
     const int lane0 = threadIdx.x & 63;
-    int e = 0, row0 = 0, rows_valid = 0, prow0 = 0, nt = 0;
+    int n_real = m_slots * n_tiles;
+    if (tpe != nullptr) {
+        // One vector load per 64 experts (every wave does it redundantly; nothing is shared).
+        int cp = 0, ct = 0;
+        for (int base = 0; base < E; base += 64) (void)expert_chunk(tpe, offs, E, T, C::BM, base, lane0, cp, ct);
+        const int m_tiles = ct < m_slots ? ct : m_slots;     // overlapping ranges: stay inside the plan
+        n_real = m_tiles * n_tiles;
+    }
+
+    n_real = __builtin_amdgcn_readfirstlane(n_real);
+  for (int vb = blockIdx.x; vb < n_real; vb += gridDim.x) {
+    int e = 0, row0 = 0, rows_valid = 0, prow0 = 0;
+    const int tile = xcd_remap(vb, n_real);
+    const int ms = tile / n_tiles;
+    const int nt = tile - ms * n_tiles;
     if (tpe == nullptr) {                                   // linear: one group covering all T rows
-        const int n_real = m_slots * n_tiles;
-        if ((int)blockIdx.x >= n_real) return;
-        const int tile = xcd_remap(blockIdx.x, n_real);
-        const int ms = tile / n_tiles;
-        nt = tile - ms * n_tiles;
         row0 = prow0 = ms * C::BM;
         rows_valid = T - row0;
-    } else {                                                // MoE: offsets/counts read on the device
-        // One vector load per 64 experts (every wave does it redundantly; nothing is shared).  With
-        // E <= 64 a single chunk gives both the total m-tile count and the owner of this m-tile.
+    } else {                                                // MoE: the expert that owns this m-tile
         int cp = 0, ct = 0;
-        const ExpertLane x0 = expert_chunk(tpe, offs, E, T, C::BM, 0, lane0, cp, ct);
-        for (int base = 64; base < E; base += 64) (void)expert_chunk(tpe, offs, E, T, C::BM, base, lane0, cp, ct);
-        const int m_tiles = ct < m_slots ? ct : m_slots;     // overlapping ranges: stay inside the grid
-        const int n_real = m_tiles * n_tiles;
-        if ((int)blockIdx.x >= n_real) return;
-        const int tile = xcd_remap(blockIdx.x, n_real);
-        const int ms = tile / n_tiles;
-        nt = tile - ms * n_tiles;
-        cp = 0; ct = 0;
         bool found = false;
         for (int base = 0; base < E && !found; base += 64) {
-            ExpertLane x = x0;
-            if (base == 0) { cp = __shfl(x0.pad_excl + (x0.cnt + FQL_MB - 1) / FQL_MB * FQL_MB, 63, 64); ct = __shfl(x0.tile_excl + x0.tiles, 63, 64); }
-            else x = expert_chunk(tpe, offs, E, T, C::BM, base, lane0, cp, ct);
+            const ExpertLane x = expert_chunk(tpe, offs, E, T, C::BM, base, lane0, cp, ct);   // re-read per tile: keeps no table live in registers
             const unsigned long long hit = __ballot(ms >= x.tile_excl && ms < x.tile_excl + x.tiles);
             if (hit) {
                 const int src = __ffsll((long long)hit) - 1;
@@ -106,9 +101,9 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_kernel(
                 found = true;
             }
         }
-        if (!found) return;
+        if (!found) continue;
     }
-    if (rows_valid <= 0) return;
+    if (rows_valid <= 0) continue;
     if (rows_valid > C::BM) rows_valid = C::BM;
     const int n0 = nt * C::BN;
     e = __builtin_amdgcn_readfirstlane(e);
@@ -142,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_kernel(
     int voffB[C::CPWB], wB[C::CPWB];
 #pragma unroll
     for (int i = 0; i < C::CPWB; ++i) {
-        const int row = (i * 8 + wave) * 8 + (lane >> 3), ch = lane & 7;
+        const int row = (i * C::NW + wave) * 8 + (lane >> 3), ch = lane & 7;
         voffB[i] = (n0 + row) * (K >> 1) + ch * 16;
         wB[i] = row * 128 + 16 * (ch ^ ((row >> 1) & 7));   // swizzled LDS image
     }
@@ -178,9 +173,6 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_kernel(
 #pragma unroll
     for (int i = 0; i < C::CPWB; ++i) bst[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], FQL_KB / 2, 0);
 
-#if defined(FQL_STAMP)
-    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
     if (active) {
 #pragma unroll
         for (int s = 0; s < D; ++s)
@@ -264,19 +256,16 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_kernel(
             wait_lgkmcnt0();
             __builtin_amdgcn_s_barrier();
         }
-        return;
+        continue;
     }
 
-#if defined(FQL_STAMP)
-    const unsigned long long st1 = __builtin_amdgcn_s_memtime(), rt1 = __builtin_amdgcn_s_memrealtime();
-#endif
     // ---- epilogue: fold zero-point, combine limbs, scale.  The weights are the MFMA's A operand (rows = n)
     //      and the activations its B operand (cols = t), so in the 32x32 C/D layout
     //      (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) every lane owns ONE output
     //      row t and registers 4q..4q+3 are 4 consecutive output columns: 4 per-row loads per lane and
     //      16-byte stores.
     const int rl = wm * FQL_MB + l31;
-    if (rl >= rows_valid) return;
+    if (rl >= rows_valid) continue;
     const int t = row0 + rl;
     const float d = delta[t];
     float rs[L];
@@ -318,12 +307,6 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_kernel(
                 }
             }
         }
-#if defined(FQL_STAMP)
-    if (blockIdx.x == 8 && lane == 0) {
-        const unsigned long long st2 = __builtin_amdgcn_s_memtime(), rt2 = __builtin_amdgcn_s_memrealtime();
-        fql_stamps[wave * 8 + 0] = st1 - st0; fql_stamps[wave * 8 + 1] = rt1 - rt0;
-        fql_stamps[wave * 8 + 2] = st2 - st1; fql_stamps[wave * 8 + 3] = rt2 - rt1;
-    }
-#endif
+  }   // persistent tile loop
 #endif  // __HIP_DEVICE_COMPILE__
 }

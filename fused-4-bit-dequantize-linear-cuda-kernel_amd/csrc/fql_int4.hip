@@ -50,14 +50,15 @@ inline Workspace carve(void *base, int L, int T, int E, int Kp)
 
 // ---- MFMA tile configurations (see fql_gemm_i8.h): 8 waves as WM x WN, NF 32-column fragments per wave.
 struct TileShape { int bm, bn; };
-#define FQL_CFG_LIST(X)  \
-    X(0, 4, 2, 3)        /* 128 x 192 */ \
-    X(1, 4, 2, 2)        /* 128 x 128 */ \
-    X(2, 4, 2, 4)        /* 128 x 256 */ \
-    X(3, 2, 4, 2)        /*  64 x 256 */ \
-    X(4, 2, 4, 1)        /*  64 x 128 */ \
-    X(5, 1, 8, 1)        /*  32 x 256 */
-constexpr int FQL_NUM_CFG = 6;
+#define FQL_CFG_LIST(X)     \
+    X(0, 4, 2, 3, 4)        /* 128 x 192, A ring 4 steps */ \
+    X(1, 4, 2, 2, 4)        /* 128 x 128 */ \
+    X(2, 4, 2, 4, 2)        /* 128 x 256 (2-limb register budget) */ \
+    X(3, 2, 4, 2, 4)        /*  64 x 256 */ \
+    X(4, 2, 4, 1, 4)        /*  64 x 128 */ \
+    X(5, 1, 8, 1, 4)        /*  32 x 256 */ \
+    X(6, 4, 2, 3, 2)        /* 128 x 192, A ring 2 steps */
+constexpr int FQL_NUM_CFG = 7;
 
 // The MFMA path addresses its operands through 32-bit buffer offsets.
 inline bool mfma_addressable(int L, int T, int E, int K, int N)
@@ -70,6 +71,20 @@ inline bool mfma_addressable(int L, int T, int E, int K, int N)
 inline bool mfma_eligible(int L, int T, int E, int K, int N, const uint8_t *packed)
 {
     return (K % 32 == 0) && aligned16(packed) && mfma_addressable(L, T, E, K, N);
+}
+
+inline int compute_units()
+{
+    static int cached = 0;                                   // idempotent; a race only repeats the query
+    if (cached == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;                                         // MI355X
+        n -= n % 8;                                          // keep vb % 8 == blockIdx % 8 (XCD grouping)
+        cached = n > 0 ? n : 8;
+    }
+    return cached;
 }
 
 template <int L>
@@ -86,13 +101,13 @@ int launch_act_quant(const float *x, const Workspace &w, int T, int K, int Kp, i
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
-template <int L, int WM, int WN, int NF>
+template <int L, int WM, int WN, int NF, int DEPTH>
 int launch_gemm_cfg(const Workspace &w, const uint8_t *packed, const float *scales, const float *zps,
                     float *out, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT, int N,
                     hipStream_t st)
 {
-    using C = GemmCfg<L, WM, WN, NF>;
-    auto kern = gemm_i8_kernel<L, WM, WN, NF>;
+    using C = GemmCfg<L, WM, WN, NF, DEPTH>;
+    auto kern = gemm_i8_kernel<L, WM, WN, NF, DEPTH>;
     static bool attr_set = false;           // idempotent; a race only repeats the same call
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -102,8 +117,10 @@ int launch_gemm_cfg(const Workspace &w, const uint8_t *packed, const float *scal
     }
     const int n_tiles = (N + C::BN - 1) / C::BN;
     const int m_slots = (tpe == nullptr) ? (T + C::BM - 1) / C::BM : T / C::BM + E;
-    const long long blocks = (long long)n_tiles * m_slots;
+    long long blocks = (long long)n_tiles * m_slots;        // worst-case tile count (real count is on the device)
     if (blocks <= 0 || blocks > 0x7fffffffLL) return FQL_ERR_BAD_SHAPE;
+    const int cus = compute_units();                         // persistent: one workgroup per CU walks the tiles
+    if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, w.limbs, w.delta, w.rowsum,
                        packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
@@ -115,9 +132,9 @@ int launch_gemm(int cfg, const Workspace &w, const uint8_t *packed, const float 
                 hipStream_t st)
 {
     switch (cfg) {
-#define X(id, wm, wn, nf)                                                                                     \
-    case id:                                                                                                  \
-        return launch_gemm_cfg<L, wm, wn, nf>(w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, st);
+#define X(id, wm, wn, nf, d)                                                                                     \
+    case id:                                                                                                     \
+        return launch_gemm_cfg<L, wm, wn, nf, d>(w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, st);
         FQL_CFG_LIST(X)
 #undef X
     default: return FQL_ERR_BAD_SHAPE;
@@ -398,11 +415,5 @@ FQL_API int fql_tune_gemm_i8_f32(int cfg, const int8_t *limbs, const float *delt
 
 FQL_API int fql_tune_num_configs(void) { return FQL_NUM_CFG; }
 
-#if defined(FQL_STAMP)
-FQL_API int fql_tune_read_stamps(unsigned long long *dst)      // diagnostic build only; synchronises
-{
-    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(fql_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
-}
-#endif
 
 }  // extern "C"
