@@ -171,25 +171,31 @@ __global__ __launch_bounds__(256) void act_limbs_kernel(
     const int gi = tid & 31;                      // 8-group inside the 256-k block
     const bool vec_ok = ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
 
-    if (tid < 64) {                               // token row of each of the block's 32 padded rows (-1: padding)
-        if (tpe == nullptr) {
-            if (tid < FQL_MB) s_tok[tid] = (mb * FQL_MB + tid < T) ? mb * FQL_MB + tid : -1;
-        } else {
-            if (tid < FQL_MB) s_tok[tid] = -1;
-            int cp = 0, ct = 0;
-            for (int base = 0; base < E; base += 64) {
+    // token row of each of the block's 32 padded rows (-1: padding)
+    if (tpe == nullptr) {
+        if (tid < FQL_MB) s_tok[tid] = (mb * FQL_MB + tid < T) ? mb * FQL_MB + tid : -1;
+    } else {
+        // wave 0 publishes the expert table chunk by chunk; 32 threads then look their row up in parallel
+        __shared__ int s_lo[64], s_cnt[64], s_pad[64];
+        int t_found = -1;
+        int cp = 0, ct = 0;
+        for (int base = 0; base < E; base += 64) {
+            if (tid < 64) {
                 const ExpertLane xl = expert_chunk(tpe, offs, E, T, FQL_MB, base, tid, cp, ct);
-                for (int r = 0; r < FQL_MB; ++r) {
-                    const int p = mb * FQL_MB + r;
-                    const unsigned long long hit = __ballot(p >= xl.pad_excl && p - xl.pad_excl < xl.cnt);
-                    if (hit) {
-                        const int src = __ffsll((long long)hit) - 1;
-                        const int tk = __shfl(xl.lo, src, 64) + p - __shfl(xl.pad_excl, src, 64);
-                        if (tid == 0 && s_tok[r] < 0) s_tok[r] = tk;
-                    }
+                s_lo[tid] = xl.lo; s_cnt[tid] = xl.cnt; s_pad[tid] = xl.pad_excl;
+            }
+            __syncthreads();
+            if (tid < FQL_MB && t_found < 0) {
+                const int p = mb * FQL_MB + tid;
+                const int ne = (E - base) < 64 ? (E - base) : 64;
+                for (int i = 0; i < ne; ++i) {
+                    const int rel = p - s_pad[i];
+                    if (rel >= 0 && rel < s_cnt[i]) { t_found = s_lo[i] + rel; break; }
                 }
             }
+            __syncthreads();
         }
+        if (tid < FQL_MB) s_tok[tid] = t_found;
     }
     __syncthreads();
 
