@@ -26,7 +26,7 @@
 #pragma once
 #include "fql_common.h"
 
-template <int L, int WM, int WN, int NF, int DEPTH>
+template <int L, int WM, int WN, int NF, int DEPTH, int BPIPE = 0>
 struct GemmCfg {
     static constexpr int NW = WM * WN;
     static constexpr int THREADS = 64 * NW;
@@ -46,7 +46,7 @@ struct GemmCfg {
 __device__ __forceinline__ void wait_lgkmcnt0() { __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14)); }
 
 
-template <int L, int WM, int WN, int NF, int DEPTH>
+template <int L, int WM, int WN, int NF, int DEPTH, int BPIPE>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_i8_kernel(
     const int8_t *__restrict__ limbs, const float *__restrict__ delta,
     const int32_t *__restrict__ rowsum, const uint8_t *__restrict__ packed,
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_i8_kernel(
     int E, int T, int K, int Kp, int MBT, int N, int n_tiles, int m_slots)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub
-    using C = GemmCfg<L, WM, WN, NF, DEPTH>;
+    using C = GemmCfg<L, WM, WN, NF, DEPTH, BPIPE>;
     constexpr int KS = C::KS, D = C::D;
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
@@ -173,7 +173,80 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_i8_kernel(
 #pragma unroll
     for (int i = 0; i < C::CPWB; ++i) bst[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], FQL_KB / 2, 0);
 
-    if (active) {
+    if (active && BPIPE) {
+        // ---- variant with the weight fragments software-pipelined one k-step ahead: the ds_reads of the
+        //      next 64-k pair and the nibble unpack of the next step are issued under the current step's
+        //      MFMAs.  One barrier per stage, placed at step 5: by then every wave has parked stage kt+1 (its
+        //      step 0) and has finished reading stage kt (the last read of it is issued at step 4).
+#pragma unroll
+        for (int s = 0; s < D; ++s)
+#pragma unroll
+            for (int l = 0; l < L; ++l) afr[s][l] = __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff[l], s * 1024, 0);
+        wait_lgkmcnt0();
+        __builtin_amdgcn_s_barrier();
+        v4i bcur[NF], bnx[NF], braw_nx[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            braw[j] = *reinterpret_cast<const v4i *>(lds + rB[j] + 16 * ((0 + g) ^ swB[j]));
+            uint32_t lo0, hi0, lo1, hi1;
+            unpack8((uint32_t)braw[j][0], lo0, hi0);
+            unpack8((uint32_t)braw[j][1], lo1, hi1);
+            bcur[j][0] = (int)lo0; bcur[j][1] = (int)hi0; bcur[j][2] = (int)lo1; bcur[j][3] = (int)hi1;
+        }
+        for (int kt = 0; kt < KT; ++kt) {
+            const char *sb = lds + (kt & 1) * C::B_STAGE;
+            char *nb = lds + ((kt + 1) & 1) * C::B_STAGE;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int v = ks >> 1, b = ks & 1;
+                if (ks == 0) {
+#pragma unroll
+                    for (int i = 0; i < C::CPWB; ++i) *reinterpret_cast<v4i *>(nb + wB[i]) = bst[i];
+#pragma unroll
+                    for (int i = 0; i < C::CPWB; ++i)
+                        bst[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], (kt + 2) * (FQL_KB / 2), 0);
+                }
+                if (ks == 5) {
+                    wait_lgkmcnt0();
+                    __builtin_amdgcn_s_barrier();
+                }
+                if (b == 0) {                  // raw weights of the NEXT pair (pair 0 of the next stage at step 6)
+                    const char *src = (v < 3) ? sb : nb;
+                    const int nv = (v + 1) & 3;
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+                        braw_nx[j] = *reinterpret_cast<const v4i *>(src + rB[j] + 16 * ((2 * nv + g) ^ swB[j]));
+                }
+#pragma unroll
+                for (int l = 0; l < L; ++l)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+                        acc[l][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bcur[j], afr[ks % D][l], acc[l][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {  // unpack for the next step under the MFMAs
+                    uint32_t lo0, hi0, lo1, hi1;
+                    if (b == 0) {
+                        unpack8((uint32_t)braw[j][2], lo0, hi0);
+                        unpack8((uint32_t)braw[j][3], lo1, hi1);
+                    } else {
+                        unpack8((uint32_t)braw_nx[j][0], lo0, hi0);
+                        unpack8((uint32_t)braw_nx[j][1], lo1, hi1);
+                        braw[j] = braw_nx[j];
+                    }
+                    bnx[j][0] = (int)lo0; bnx[j][1] = (int)hi0; bnx[j][2] = (int)lo1; bnx[j][3] = (int)hi1;
+                }
+                const int nks = ks + D;
+#pragma unroll
+                for (int l = 0; l < L; ++l)
+                    afr[ks % D][l] = __builtin_amdgcn_raw_buffer_load_b128(
+                        rsA, aoff[l], (kt + nks / KS) * a_stage + (nks % KS) * 1024, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < NF; ++j) bcur[j] = bnx[j];
+            }
+        }
+        wait_lgkmcnt0();
+    } else if (active) {
 #pragma unroll
         for (int s = 0; s < D; ++s)
 #pragma unroll

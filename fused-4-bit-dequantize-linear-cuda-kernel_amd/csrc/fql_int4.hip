@@ -50,15 +50,19 @@ inline Workspace carve(void *base, int L, int T, int E, int Kp)
 
 // ---- MFMA tile configurations (see fql_gemm_i8.h): 8 waves as WM x WN, NF 32-column fragments per wave.
 struct TileShape { int bm, bn; };
-#define FQL_CFG_LIST(X)     \
-    X(0, 4, 2, 3, 4)        /* 128 x 192, A ring 4 steps */ \
-    X(1, 4, 2, 2, 4)        /* 128 x 128 */ \
-    X(2, 4, 2, 4, 2)        /* 128 x 256 (2-limb register budget) */ \
-    X(3, 2, 4, 2, 4)        /*  64 x 256 */ \
-    X(4, 2, 4, 1, 4)        /*  64 x 128 */ \
-    X(5, 1, 8, 1, 4)        /*  32 x 256 */ \
-    X(6, 4, 2, 3, 2)        /* 128 x 192, A ring 2 steps */
-constexpr int FQL_NUM_CFG = 7;
+#define FQL_CFG_LIST(X)        \
+    X(0, 4, 2, 3, 4, 0)        /* 128 x 192, A ring 4 steps */ \
+    X(1, 4, 2, 2, 4, 0)        /* 128 x 128 */ \
+    X(2, 4, 2, 4, 2, 0)        /* 128 x 256 (2-limb register budget) */ \
+    X(3, 2, 4, 2, 4, 0)        /*  64 x 256 */ \
+    X(4, 2, 4, 1, 4, 0)        /*  64 x 128 */ \
+    X(5, 1, 8, 1, 4, 0)        /*  32 x 256 */ \
+    X(6, 4, 2, 3, 2, 0)        /* 128 x 192, A ring 2 steps */ \
+    X(7, 4, 2, 3, 2, 1)        /* 128 x 192, A ring 2 steps, weight fragments pipelined one step ahead */ \
+    X(8, 4, 2, 2, 4, 1)        /* 128 x 128, pipelined */ \
+    X(9, 4, 2, 3, 4, 1)        /* 128 x 192, A ring 4 steps, pipelined (2-limb register budget) */ \
+    X(10, 2, 4, 2, 4, 1)       /*  64 x 256, pipelined */
+constexpr int FQL_NUM_CFG = 11;
 
 // The MFMA path addresses its operands through 32-bit buffer offsets.
 inline bool mfma_addressable(int L, int T, int E, int K, int N)
@@ -101,13 +105,13 @@ int launch_act_quant(const float *x, const Workspace &w, int T, int K, int Kp, i
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
-template <int L, int WM, int WN, int NF, int DEPTH>
+template <int L, int WM, int WN, int NF, int DEPTH, int BPIPE>
 int launch_gemm_cfg(const Workspace &w, const uint8_t *packed, const float *scales, const float *zps,
                     float *out, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT, int N,
                     hipStream_t st)
 {
-    using C = GemmCfg<L, WM, WN, NF, DEPTH>;
-    auto kern = gemm_i8_kernel<L, WM, WN, NF, DEPTH>;
+    using C = GemmCfg<L, WM, WN, NF, DEPTH, BPIPE>;
+    auto kern = gemm_i8_kernel<L, WM, WN, NF, DEPTH, BPIPE>;
     static bool attr_set = false;           // idempotent; a race only repeats the same call
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -132,9 +136,9 @@ int launch_gemm(int cfg, const Workspace &w, const uint8_t *packed, const float 
                 hipStream_t st)
 {
     switch (cfg) {
-#define X(id, wm, wn, nf, d)                                                                                     \
-    case id:                                                                                                     \
-        return launch_gemm_cfg<L, wm, wn, nf, d>(w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, st);
+#define X(id, wm, wn, nf, d, bp)                                                                                  \
+    case id:                                                                                                      \
+        return launch_gemm_cfg<L, wm, wn, nf, d, bp>(w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, st);
         FQL_CFG_LIST(X)
 #undef X
     default: return FQL_ERR_BAD_SHAPE;
@@ -152,13 +156,17 @@ inline int choose_cfg(int L, int E, int T, int K, int N, bool grouped)
     const int groups = grouped ? (E > 0 ? E : 1) : 1;
     const int m = (T + groups - 1) / groups;                 // rows per group if evenly routed
     if (m <= 32) return 5;                                   //  32 x 256
-    if (m <= 64) return 3;                                   //  64 x 256
+    if (m <= 64) return 10;                                  //  64 x 256, weight fragments pipelined
     const int mt = groups * ((m + 127) / 128);
     struct Cand { int cfg, bn; };
-    const Cand cands[3] = {{0, 192}, {1, 128}, {2, 256}};
-    int best = 0;
+    // 3 limbs: 128 x 192 with a 2-step A ring (register budget) / 128 x 128; 2 limbs: 4-step ring, + 128 x 256
+    const Cand c3[2] = {{7, 192}, {8, 128}};
+    const Cand c2[3] = {{9, 192}, {8, 128}, {2, 256}};
+    const Cand *cands = (L == 2) ? c2 : c3;
+    const int nc = (L == 2) ? 3 : 2;
+    int best = cands[0].cfg;
     long long best_cost = -1;
-    for (int i = 0; i < (L == 2 ? 3 : 2); ++i) {             // 128 x 256 needs the 2-limb register budget
+    for (int i = 0; i < nc; ++i) {
         const long long tiles = (long long)mt * ((N + cands[i].bn - 1) / cands[i].bn);
         const long long rounds = (tiles + 255) / 256;
         const long long cost = rounds * (cands[i].bn + 24);  // +24: per-tile prologue / epilogue
