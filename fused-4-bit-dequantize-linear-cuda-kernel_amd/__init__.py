@@ -8,11 +8,11 @@ from .quantize import quantize_weights, dequantize_weights, reference_quantized_
 from .module import QuantizedLinear
 from .moe import MoEINT4, quantize_weights_moe, QuantizedMoE, QuantizedMoEExpert
 from .routing import (RoutingResult, simulate_routing, balanced_routing, create_expert_inputs,
-                      combine_expert_outputs, dispatch_grouped, combine_grouped)
+                      combine_expert_outputs, dispatch_grouped, dispatch_indices, combine_grouped)
 
 __all__ = [
     "quantize_weights", "dequantize_weights", "reference_quantized_linear", "QuantizedLinear",
     "MoEINT4", "quantize_weights_moe", "QuantizedMoE", "QuantizedMoEExpert",
     "RoutingResult", "simulate_routing", "balanced_routing", "create_expert_inputs",
-    "combine_expert_outputs", "dispatch_grouped", "combine_grouped",
+    "combine_expert_outputs", "dispatch_grouped", "dispatch_indices", "combine_grouped",
 ]

@@ -31,6 +31,8 @@ _SYMBOLS = {
     "fql_moe_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 5),
     "fql_moe_fwd_f32": (ctypes.c_int, [ctypes.c_void_p] * 7 + [ctypes.c_int] * 5
                         + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "fql_moe_gather_fwd_f32": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] + [ctypes.c_void_p] * 3
+                               + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "fql_unpack_u8": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "fql_dequantize_f32": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),
     "fql_act_padded_k": (ctypes.c_int, [ctypes.c_int]),

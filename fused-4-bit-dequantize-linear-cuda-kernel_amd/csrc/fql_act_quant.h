@@ -23,6 +23,17 @@
 #include "fql_common.h"
 #include <math.h>
 
+// Fused dispatch: when `gather` is given, grouped row t is read from token row
+// gather[t] of x (the sort-by-expert permutation of routing.py:117-149), so the [T*top_k, K] gathered
+// copy of the activations is never materialised.  Indices are clamped into [0, n_src).
+__device__ __forceinline__ int source_row(const int32_t *gather, int n_src, int t)
+{
+    if (gather == nullptr) return t;
+    int s = gather[t];
+    s = s < 0 ? 0 : s;
+    return s < n_src ? s : n_src - 1;
+}
+
 template <int L> struct LimbLimit;
 template <> struct LimbLimit<1> { static constexpr int value = 127; };
 template <> struct LimbLimit<2> { static constexpr int value = 127 * 256 + 127; };
@@ -46,7 +57,8 @@ __device__ __forceinline__ int act_exponent(float m)
 //      semantics: torch::zeros, csrc/moe_int4_kernel.cu:109).
 template <int L>
 __global__ __launch_bounds__(256) void act_scale_kernel(
-    const float *__restrict__ x, float *__restrict__ delta, int32_t *__restrict__ rowsum, int T, int K,
+    const float *__restrict__ x, const int32_t *__restrict__ gather, int n_src, float *__restrict__ delta,
+    int32_t *__restrict__ rowsum, int T, int K,
     float *__restrict__ out, int N, const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs, int E)
 {
     __shared__ float s_red[4];
@@ -68,7 +80,7 @@ __global__ __launch_bounds__(256) void act_scale_kernel(
             return;
         }
     }
-    const float *xr = x + (size_t)t * K;
+    const float *xr = x + (size_t)source_row(gather, n_src, t) * K;
     const bool vec_ok = ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     float m = 0.0f;
     int bad = 0;
@@ -160,8 +172,8 @@ __global__ __launch_bounds__(256) void act_scale_kernel(
 //      16-byte stores.
 template <int L>
 __global__ __launch_bounds__(256) void act_limbs_kernel(
-    const float *__restrict__ x, const float *__restrict__ delta, int8_t *__restrict__ limbs,
-    int T, int K, int KB, int MBT,
+    const float *__restrict__ x, const int32_t *__restrict__ gather, int n_src,
+    const float *__restrict__ delta, int8_t *__restrict__ limbs, int T, int K, int KB, int MBT,
     const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs, int E)
 {
     __shared__ __attribute__((aligned(16))) char img[L * 8192];
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(256) void act_limbs_kernel(
         va[j] = vb[j] = v4f{0.f, 0.f, 0.f, 0.f};
         inv[j] = 0.0f;
         if (tok[j] >= 0) {
-            const float *xr = x + (size_t)tok[j] * K;
+            const float *xr = x + (size_t)source_row(gather, n_src, tok[j]) * K;
             if (vec_ok && k0 + 8 <= K) {
                 va[j] = *reinterpret_cast<const v4f *>(xr + k0);
                 vb[j] = *reinterpret_cast<const v4f *>(xr + k0 + 4);

@@ -92,16 +92,16 @@ inline int compute_units()
 }
 
 template <int L>
-int launch_act_quant(const float *x, const Workspace &w, int T, int K, int Kp, int MBT, float *out, int N,
-                     const int32_t *tpe, const int32_t *offs, int E, hipStream_t st)
+int launch_act_quant(const float *x, const int32_t *gather, int n_src, const Workspace &w, int T, int K, int Kp,
+                     int MBT, float *out, int N, const int32_t *tpe, const int32_t *offs, int E, hipStream_t st)
 {
-    hipLaunchKernelGGL((act_scale_kernel<L>), dim3(T), dim3(256), 0, st, x, w.delta, w.rowsum, T, K, out, N,
-                       tpe, offs, E);
+    hipLaunchKernelGGL((act_scale_kernel<L>), dim3(T), dim3(256), 0, st, x, gather, n_src, w.delta, w.rowsum, T, K,
+                       out, N, tpe, offs, E);
     if (hipGetLastError() != hipSuccess) return FQL_ERR_LAUNCH;
     // 32-row blocks that can hold real rows: every expert's rows rounded up to 32
     const int mblocks = (tpe == nullptr) ? (T + FQL_MB - 1) / FQL_MB : (T + FQL_MB * E) / FQL_MB;
-    hipLaunchKernelGGL((act_limbs_kernel<L>), dim3(mblocks, Kp / FQL_KB), dim3(256), 0, st, x, w.delta, w.limbs,
-                       T, K, Kp / FQL_KB, MBT, tpe, offs, E);
+    hipLaunchKernelGGL((act_limbs_kernel<L>), dim3(mblocks, Kp / FQL_KB), dim3(256), 0, st, x, gather, n_src, w.delta,
+                       w.limbs, T, K, Kp / FQL_KB, MBT, tpe, offs, E);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
@@ -175,7 +175,7 @@ inline int choose_cfg(int L, int E, int T, int K, int N, bool grouped)
     return best;
 }
 
-int run_mfma(int L, const float *x, const uint8_t *packed, const float *scales, const float *zps, float *out,
+int run_mfma(int L, const float *x, const int32_t *gather, int n_src, const uint8_t *packed, const float *scales, const float *zps, float *out,
              const int32_t *tpe, const int32_t *offs, int E, int T, int K, int N, void *workspace,
              size_t workspace_bytes, hipStream_t st)
 {
@@ -188,11 +188,11 @@ int run_mfma(int L, const float *x, const uint8_t *packed, const float *scales, 
     const int cfg = choose_cfg(L, E, T, K, N, tpe != nullptr);
     int rc;
     if (L == 2) {
-        rc = launch_act_quant<2>(x, w, T, K, Kp, MBT, zero_out, N, tpe, offs, E, st);
+        rc = launch_act_quant<2>(x, gather, n_src, w, T, K, Kp, MBT, zero_out, N, tpe, offs, E, st);
         if (rc != FQL_OK) return rc;
         return launch_gemm<2>(cfg, w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, st);
     }
-    rc = launch_act_quant<3>(x, w, T, K, Kp, MBT, zero_out, N, tpe, offs, E, st);
+    rc = launch_act_quant<3>(x, gather, n_src, w, T, K, Kp, MBT, zero_out, N, tpe, offs, E, st);
     if (rc != FQL_OK) return rc;
     return launch_gemm<3>(cfg, w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, st);
 }
@@ -295,17 +295,18 @@ int fql_linear_fwd_f32(const float *x, const uint8_t *packed, const float *scale
         return run_generic(x, packed, scales, zps, out, nullptr, nullptr, 1, B, K, N, st);
     }
     if (mfma_eligible(L, B, 1, K, N, packed))
-        return run_mfma(L, x, packed, scales, zps, out, nullptr, nullptr, 1, B, K, N, workspace, workspace_bytes, st);
+        return run_mfma(L, x, nullptr, 0, packed, scales, zps, out, nullptr, nullptr, 1, B, K, N, workspace, workspace_bytes, st);
     return run_generic(x, packed, scales, zps, out, nullptr, nullptr, 1, B, K, N, st);
 }
 
-int fql_moe_fwd_f32(const uint8_t *packed, const float *scales, const float *zps, const float *inputs,
-                    const int32_t *tokens_per_expert, const int32_t *input_offsets, float *out, int E, int T,
-                    int K, int N, int precision, void *workspace, size_t workspace_bytes, void *stream)
+static int moe_entry(const uint8_t *packed, const float *scales, const float *zps, const float *inputs,
+                     const int32_t *row_index, int n_src, const int32_t *tokens_per_expert,
+                     const int32_t *input_offsets, float *out, int E, int T, int K, int N, int precision,
+                     void *workspace, size_t workspace_bytes, void *stream)
 {
     const int L = limbs_of(precision);
     if (L < 0) return FQL_ERR_BAD_PRECISION;
-    if (E < 0 || T < 0 || K < 0 || N < 0) return FQL_ERR_BAD_SHAPE;
+    if (E < 0 || T < 0 || K < 0 || N < 0 || (row_index != nullptr && n_src <= 0)) return FQL_ERR_BAD_SHAPE;
     if (K & 1) return FQL_ERR_ODD_K;
     if (T == 0 || N == 0) return FQL_OK;
     if (!out) return FQL_ERR_NULL_POINTER;
@@ -316,9 +317,28 @@ int fql_moe_fwd_f32(const uint8_t *packed, const float *scales, const float *zps
     if (!packed || !scales || !zps || !inputs || !tokens_per_expert || !input_offsets) return FQL_ERR_NULL_POINTER;
     if (E > 65535) return FQL_ERR_BAD_SHAPE;
     if (mfma_eligible(L, T, E, K, N, packed))
-        return run_mfma(L, inputs, packed, scales, zps, out, tokens_per_expert, input_offsets, E, T, K, N,
-                        workspace, workspace_bytes, st);
+        return run_mfma(L, inputs, row_index, n_src, packed, scales, zps, out, tokens_per_expert, input_offsets, E, T,
+                        K, N, workspace, workspace_bytes, st);
+    if (row_index != nullptr) return FQL_ERR_ALIGNMENT;     // the fused gather exists on the MFMA path only
     return run_generic(inputs, packed, scales, zps, out, tokens_per_expert, input_offsets, E, T, K, N, st);
+}
+
+int fql_moe_fwd_f32(const uint8_t *packed, const float *scales, const float *zps, const float *inputs,
+                    const int32_t *tokens_per_expert, const int32_t *input_offsets, float *out, int E, int T,
+                    int K, int N, int precision, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return moe_entry(packed, scales, zps, inputs, nullptr, 0, tokens_per_expert, input_offsets, out, E, T, K, N,
+                     precision, workspace, workspace_bytes, stream);
+}
+
+int fql_moe_gather_fwd_f32(const uint8_t *packed, const float *scales, const float *zps, const float *tokens,
+                           const int32_t *row_index, int n_tokens, const int32_t *tokens_per_expert,
+                           const int32_t *input_offsets, float *out, int E, int T, int K, int N, int precision,
+                           void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!row_index) return FQL_ERR_NULL_POINTER;
+    return moe_entry(packed, scales, zps, tokens, row_index, n_tokens, tokens_per_expert, input_offsets, out, E, T, K,
+                     N, precision, workspace, workspace_bytes, stream);
 }
 
 int fql_unpack_u8(const uint8_t *packed, uint8_t *q, size_t nbytes, void *stream)
@@ -368,8 +388,8 @@ int fql_act_quant_f32(const float *x, int8_t *limbs, float *delta, int32_t *rows
     w.limbs = limbs; w.delta = delta; w.rowsum = rowsum; w.bytes = 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int Kp = padded_k(K), MBT = row_blocks(T, E);
-    if (L == 2) return launch_act_quant<2>(x, w, T, K, Kp, MBT, nullptr, 0, tokens_per_expert, input_offsets, E, st);
-    return launch_act_quant<3>(x, w, T, K, Kp, MBT, nullptr, 0, tokens_per_expert, input_offsets, E, st);
+    if (L == 2) return launch_act_quant<2>(x, nullptr, 0, w, T, K, Kp, MBT, nullptr, 0, tokens_per_expert, input_offsets, E, st);
+    return launch_act_quant<3>(x, nullptr, 0, w, T, K, Kp, MBT, nullptr, 0, tokens_per_expert, input_offsets, E, st);
 }
 
 static int gemm_i8_entry(int cfg, const int8_t *limbs, const float *delta, const int32_t *rowsum,

@@ -138,6 +138,42 @@ def moe_forward(packed_weights, scales, zero_points, inputs, expert_ids, tokens_
     return out
 
 
+def moe_gather_forward(packed_weights, scales, zero_points, tokens, row_index, tokens_per_expert,
+                       input_offsets, precision="default"):
+    """Grouped per-expert INT4 GEMM with the dispatch gather fused in: grouped row t = tokens[row_index[t]].
+
+    ``tokens`` [n_tokens, K] float32 in token order, ``row_index`` [T] int32 (e.g. from
+    ``routing.dispatch_indices``).  Returns the grouped outputs [T, N]; un-sort / combine with
+    ``routing.combine_grouped``.  The [T, K] gathered activations are never materialised."""
+    for name, t in (("packed_weights", packed_weights), ("tokens", tokens), ("row_index", row_index),
+                    ("tokens_per_expert", tokens_per_expert), ("input_offsets", input_offsets)):
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} must be a CUDA tensor")
+    if tokens.dtype != torch.float32 or tokens.dim() != 2:
+        raise RuntimeError("tokens must be float32 [n_tokens, hidden_dim]")
+    E, N, packed_dim = packed_weights.shape
+    n_tokens, K = tokens.shape
+    if K % 32 != 0 or packed_dim != K // 2:
+        raise RuntimeError("fused gather needs hidden_dim % 32 == 0 and packed_weights dim 2 == hidden_dim / 2")
+    T = row_index.numel()
+    dev = tokens.device
+    ri = row_index.to(torch.int32).contiguous()
+    tpe = tokens_per_expert.to(torch.int32).contiguous()
+    offs = input_offsets.to(torch.int32).contiguous()
+    tokens = tokens.contiguous()
+    L = _native.lib()
+    prec = _precision(precision)
+    out = torch.empty((T, N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws, ws_ptr = _workspace(L.fql_moe_workspace_bytes(E, T, K, N, prec), dev)
+        rc = L.fql_moe_gather_fwd_f32(packed_weights.contiguous().data_ptr(), scales.contiguous().data_ptr(),
+                                      zero_points.contiguous().data_ptr(), tokens.data_ptr(), ri.data_ptr(), n_tokens,
+                                      tpe.data_ptr(), offs.data_ptr(), out.data_ptr(), E, T, K, N, prec,
+                                      ws_ptr, 0 if ws is None else ws.numel(), _stream_ptr(dev))
+    _native.check(rc, "fql_moe_gather_fwd_f32")
+    return out
+
+
 def unpack_nibbles(packed):
     """q[..., 2j] = packed[..., j] & 15; q[..., 2j+1] = packed[..., j] >> 4 on the device."""
     if not packed.is_cuda or packed.dtype != torch.uint8:

@@ -90,6 +90,16 @@ def dispatch_grouped(x: torch.Tensor, expert_indices: torch.Tensor, num_experts:
     return grouped, tpe, offs, inverse
 
 
+def dispatch_indices(expert_indices: torch.Tensor, num_experts: int):
+    """Dispatch without moving any activation: ``(row_index int32 [T*top_k], tokens_per_expert,
+    input_offsets, inverse)`` -- feed ``row_index`` to ``ops.moe_gather_forward`` and the gather is done
+    inside the activation pre-pass."""
+    _, token_of_slot, inverse = _sort_by_expert(expert_indices)
+    tpe = torch.bincount(expert_indices.reshape(-1), minlength=num_experts).to(torch.int32)
+    offs = (torch.cumsum(tpe, 0) - tpe).to(torch.int32)
+    return token_of_slot.to(torch.int32), tpe, offs, inverse
+
+
 def create_expert_inputs(x: torch.Tensor, routing: RoutingResult, num_experts: int,
                          top_k: int) -> Tuple[List[torch.Tensor], torch.Tensor]:
     """Reference-shaped dispatch: a list of ``[m_e, K]`` tensors and the un-sort permutation."""

@@ -108,6 +108,20 @@ FQL_API int fql_moe_fwd_f32(const uint8_t *packed, const float *scales, const fl
                     int precision, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Same, with the dispatch gather fused into the activation pre-pass:
+ * grouped row t is read from tokens[row_index[t]] -- the sort-by-expert permutation of
+ * benchmark/moe_grouped_gemm/routing.py:117-149 -- so the [T, K] gathered copy of the activations is
+ * never written or re-read.  tokens [n_tokens][K] float32, row_index [T] int32 (device), values
+ * clamped into [0, n_tokens).  Requires the MFMA path (K % 32 == 0, 16-byte aligned `packed`),
+ * otherwise FQL_ERR_ALIGNMENT.  Workspace: fql_moe_workspace_bytes(E, T, K, N, precision).
+ * ------------------------------------------------------------------------------------- */
+FQL_API int fql_moe_gather_fwd_f32(const uint8_t *packed, const float *scales, const float *zps,
+                                   const float *tokens, const int32_t *row_index, int n_tokens,
+                                   const int32_t *tokens_per_expert, const int32_t *input_offsets,
+                                   float *out, int E, int T, int K, int N, int precision,
+                                   void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Format helpers on the device (same unpack code path as the GEMM kernels; bit-exact).
  *   fql_unpack_u8     : q[i][2j] = packed[i][j] & 15, q[i][2j+1] = packed[i][j] >> 4
  *                       (python/quantize.py:152-163)

@@ -367,6 +367,31 @@ def test_moeint4_module_per_tensor(fq):
     assert rel_fro(out, ref) < EXACT_REL_FRO
 
 
+def test_fused_dispatch_gather_equals_materialised(fq):
+    """gather fused into the pre-pass == index_select + grouped GEMM, bit for bit, and the
+    whole dispatch -> GEMM -> combine round trip matches the CPU oracle of routing.py semantics."""
+    from fused_int4_amd import ops
+    E, K, N, Ttok, top_k = 8, 512, 384, 96, 2
+    P, S, Z, _, _, _ = make_moe(E, N, K, [1] * E, 31)
+    r = fq.simulate_routing(Ttok, E, top_k, "skewed", device="cuda", seed=3)
+    x = torch.randn(Ttok, K, device="cuda")
+    grouped, tpe, offs, inv = fq.dispatch_grouped(x, r.expert_indices, E)
+    ref = ops.moe_forward(dev(P), dev(S), dev(Z), grouped.contiguous(), None, tpe, offs)
+    ri, tpe2, offs2, inv2 = fq.dispatch_indices(r.expert_indices, E)
+    got = ops.moe_gather_forward(dev(P), dev(S), dev(Z), x, ri, tpe2, offs2)
+    assert torch.equal(tpe, tpe2) and torch.equal(offs, offs2) and torch.equal(inv, inv2)
+    assert torch.equal(got, ref)
+    y = fq.combine_grouped(got, r.expert_weights, inv2, top_k).cpu().numpy()
+    gx, cnt, of, oinv = O.create_expert_inputs(x.cpu().numpy(), r.expert_indices.cpu().numpy(), E)
+    oy = C.moe_grouped(P, S, Z, gx, cnt, of)
+    yref = O.combine_expert_outputs(oy, r.expert_weights.cpu().numpy(), oinv, top_k)
+    assert rel_fro(y, yref) < 5e-6
+    # out-of-range indices are clamped, not dereferenced
+    bad = ri.clone(); bad[0] = 10 ** 6; bad[1] = -5
+    ops.moe_gather_forward(dev(P), dev(S), dev(Z), x, bad, tpe2, offs2)
+    torch.cuda.synchronize()
+
+
 def test_moe_clipping_of_bad_ranges(fq):
     """Offsets / counts that leave [0, T] are clipped on the device; nothing faults."""
     from fused_int4_amd import ops
