@@ -8,6 +8,7 @@
 #include "fql_gemm_i8.h"
 #include "fql_gemv.h"
 #include "fql_generic.h"
+#include "fql_quantize.h"
 
 namespace {
 
@@ -390,6 +391,31 @@ int fql_act_quant_f32(const float *x, int8_t *limbs, float *delta, int32_t *rows
     const int Kp = padded_k(K), MBT = row_blocks(T, E);
     if (L == 2) return launch_act_quant<2>(x, nullptr, 0, w, T, K, Kp, MBT, nullptr, 0, tokens_per_expert, input_offsets, E, st);
     return launch_act_quant<3>(x, nullptr, 0, w, T, K, Kp, MBT, nullptr, 0, tokens_per_expert, input_offsets, E, st);
+}
+
+int fql_quantize_rows_f32(const float *w, uint8_t *packed, float *scales, float *zps, int N, int K, void *stream)
+{
+    if (N < 0 || K < 0) return FQL_ERR_BAD_SHAPE;
+    if (K & 1) return FQL_ERR_ODD_K;
+    if (N == 0 || K == 0) return FQL_OK;
+    if (!w || !packed || !scales || !zps) return FQL_ERR_NULL_POINTER;
+    hipLaunchKernelGGL(quantize_rows_kernel, dim3(N), dim3(256), 0, static_cast<hipStream_t>(stream), w, N, K, packed,
+                       scales, zps);
+    return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
+}
+
+int fql_quantize_tensor_f32(const float *w, uint8_t *packed, float *scales, float *zps, float *scratch, int N, int K,
+                            void *stream)
+{
+    if (N < 0 || K < 0) return FQL_ERR_BAD_SHAPE;
+    if (K & 1) return FQL_ERR_ODD_K;
+    if (N == 0 || K == 0) return FQL_OK;
+    if (!w || !packed || !scales || !zps || !scratch) return FQL_ERR_NULL_POINTER;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(row_minmax_kernel, dim3(N), dim3(256), 0, st, w, N, K, scratch, scratch + N);
+    hipLaunchKernelGGL(tensor_scale_kernel, dim3(1), dim3(256), 0, st, scratch, scratch + N, N, scales, zps);
+    hipLaunchKernelGGL(quantize_given_kernel, dim3(N), dim3(256), 0, st, w, N, K, scales, zps, packed);
+    return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
 static int gemm_i8_entry(int cfg, const int8_t *limbs, const float *delta, const int32_t *rowsum,

@@ -42,6 +42,10 @@ def quantize_weights_moe(weights_list):
     zero_points = torch.zeros(E, N, dtype=torch.float32, device=device)
     for e, w in enumerate(weights_list):
         w32 = w.float()
+        if w32.is_cuda:                             # HIP quantiser: bit-exact with the host arithmetic below
+            from . import ops
+            packed[e], scales[e], zero_points[e] = ops.quantize_tensor(w32)
+            continue
         lo, hi = torch.aminmax(w32)
         scale = ((hi - lo) / 15.0).item()
         zp = float(max(0, min(15, round((-lo / scale).item()))))

@@ -174,6 +174,39 @@ def moe_gather_forward(packed_weights, scales, zero_points, tokens, row_index, t
     return out
 
 
+def quantize_rows(weight_fp32):
+    """GPU quantize_weights (python/quantize.py:38-124), bit-exact with the host arithmetic."""
+    if not weight_fp32.is_cuda or weight_fp32.dtype != torch.float32 or weight_fp32.dim() != 2:
+        raise RuntimeError("weight must be a CUDA float32 [N,K] tensor")
+    w = weight_fp32.contiguous()
+    N, K = w.shape
+    packed = torch.empty((N, K // 2), dtype=torch.uint8, device=w.device)
+    scales = torch.empty((N,), dtype=torch.float32, device=w.device)
+    zps = torch.empty((N,), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = _native.lib().fql_quantize_rows_f32(w.data_ptr(), packed.data_ptr(), scales.data_ptr(), zps.data_ptr(),
+                                                 N, K, _stream_ptr(w.device))
+    _native.check(rc, "fql_quantize_rows_f32")
+    return packed, scales, zps
+
+
+def quantize_tensor(weight_fp32):
+    """GPU per-tensor quantiser of one expert (python/moe_int4_module.py:45-76): scale / zp broadcast to [N]."""
+    if not weight_fp32.is_cuda or weight_fp32.dtype != torch.float32 or weight_fp32.dim() != 2:
+        raise RuntimeError("weight must be a CUDA float32 [N,K] tensor")
+    w = weight_fp32.contiguous()
+    N, K = w.shape
+    packed = torch.empty((N, K // 2), dtype=torch.uint8, device=w.device)
+    scales = torch.empty((N,), dtype=torch.float32, device=w.device)
+    zps = torch.empty((N,), dtype=torch.float32, device=w.device)
+    scratch = torch.empty((2 * N,), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        rc = _native.lib().fql_quantize_tensor_f32(w.data_ptr(), packed.data_ptr(), scales.data_ptr(), zps.data_ptr(),
+                                                   scratch.data_ptr(), N, K, _stream_ptr(w.device))
+    _native.check(rc, "fql_quantize_tensor_f32")
+    return packed, scales, zps
+
+
 def unpack_nibbles(packed):
     """q[..., 2j] = packed[..., j] & 15; q[..., 2j+1] = packed[..., j] >> 4 on the device."""
     if not packed.is_cuda or packed.dtype != torch.uint8:

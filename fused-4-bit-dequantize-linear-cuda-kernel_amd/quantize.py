@@ -46,6 +46,9 @@ def quantize_weights(weight_fp32: torch.Tensor, num_bits: int = 4):
     """
     assert weight_fp32.ndim == 2, "Weight must be 2D [output_dim, input_dim]"
     assert weight_fp32.shape[1] % 2 == 0, "input_dim must be even for packing"
+    if weight_fp32.is_cuda and num_bits == 4 and weight_fp32.dtype == torch.float32:
+        from . import ops                       # HIP quantiser: bit-exact with the host path below
+        return ops.quantize_rows(weight_fp32)
     qmax = (1 << num_bits) - 1
     lo, hi = torch.aminmax(weight_fp32, dim=1)
     span_scale = (hi - lo) / qmax

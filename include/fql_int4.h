@@ -133,6 +133,20 @@ FQL_API int fql_dequantize_f32(const uint8_t *packed, const float *scales, const
                        int N, int K, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Quantisers on the device, bit-exact with the reference's host arithmetic:
+ *   fql_quantize_rows_f32   : python/quantize.py:38-124  per-ROW scale / zero-point (constant-row guard,
+ *                             1e-8 floor, round-half-to-even), packed [N][K/2], scales / zps [N]
+ *   fql_quantize_tensor_f32 : python/moe_int4_module.py:45-76  per-TENSOR scale / zero-point broadcast to
+ *                             [N] (one expert); scratch = 2*N floats of device memory
+ *   w [N][K] float32 contiguous (fp16 weights are widened by the caller, as the reference does).
+ * ------------------------------------------------------------------------------------- */
+FQL_API int fql_quantize_rows_f32(const float *w, uint8_t *packed, float *scales, float *zps, int N, int K,
+                                  void *stream);
+
+FQL_API int fql_quantize_tensor_f32(const float *w, uint8_t *packed, float *scales, float *zps,
+                                    float *scratch, int N, int K, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Phase 1 of the MFMA path on its own: the activation pre-pass (also the tests' window into it).
  *   x[t][k] ~= delta[t] * sum_l 256^l * a_l[t][k],  a_l signed 8-bit ("limbs"), delta a power of two
  *   limbs   fql_act_limb_bytes(T, E, K, precision) bytes, 16-byte aligned, in MFMA-fragment order:

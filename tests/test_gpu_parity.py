@@ -105,6 +105,32 @@ def test_activation_limbs_grouped_layout(fq):
     assert np.array_equal(delta.cpu().numpy()[covered], ref_delta[covered])
 
 
+def test_gpu_quantisers_bit_exact(fq):
+    """weights quantised on the GPU == weights quantised by the reference on the host."""
+    from fused_int4_amd import ops
+    for name in ("f1_quant_16x32", "f2_linear_64x128"):
+        g = load_golden(name)
+        p, s, z = ops.quantize_rows(dev(g["weight"]))
+        assert np.array_equal(p.cpu().numpy(), g["packed"])
+        assert np.array_equal(s.cpu().numpy(), g["scales"]) and np.array_equal(z.cpu().numpy(), g["zero_points"])
+    g = load_golden("f4_constant_rows")
+    for sfx in ("", "2"):
+        p, s, z = fq.quantize_weights(dev(g["weight" + sfx]))           # package API dispatches to the HIP kernel
+        assert np.array_equal(p.cpu().numpy(), g["packed" + sfx])
+        assert np.array_equal(s.cpu().numpy(), g["scales" + sfx]) and np.array_equal(z.cpu().numpy(), g["zero_points" + sfx])
+    rng = np.random.default_rng(8)
+    w = (rng.standard_normal((300, 1030)) * 0.02).astype(np.float32)
+    w[5] = 0.5; w[6, ::2] = -1.0; w[6, 1::2] = 1.0
+    p, s, z = ops.quantize_rows(dev(w))
+    rp, rs, rz = O.quantize_weights(w)
+    assert np.array_equal(p.cpu().numpy(), rp) and np.array_equal(s.cpu().numpy(), rs) and np.array_equal(z.cpu().numpy(), rz)
+    g = load_golden("f7_moe_per_tensor")
+    for sfx in ("", "2"):
+        pk, sc, zp = fq.quantize_weights_moe([torch.from_numpy(x).cuda() for x in g["weights" + sfx]])
+        assert np.array_equal(pk.cpu().numpy(), g["packed" + sfx])
+        assert np.array_equal(sc.cpu().numpy(), g["scales" + sfx]) and np.array_equal(zp.cpu().numpy(), g["zero_points" + sfx])
+
+
 # ------------------------------------------------------------------------------ linear: reference's own cases
 def test_golden_f2_64x128_1d(fq):
     """tests/test_correctness.py:201-219 (atol=1e-3) through the drop-in operator name."""
@@ -350,11 +376,7 @@ def test_moe_golden_f8_quantized_moe(fq):
 def test_moeint4_module_per_tensor(fq):
     """MoEINT4 (python/moe_int4_module.py:83-146): per-tensor quantiser + grouped forward."""
     g = load_golden("f7_moe_per_tensor")
-    # quantise on the CPU (where the golden vectors were made: GPU float division may differ by 1 ulp),
-    # then move the module -- the usual construction path
-    mod = fq.MoEINT4.from_weights([torch.from_numpy(w) for w in g["weights"]]).cuda()
-    gpu_q = fq.quantize_weights_moe([torch.from_numpy(w).cuda() for w in g["weights"]])
-    assert np.allclose(gpu_q[1].cpu().numpy(), g["scales"], rtol=1e-6)
+    mod = fq.MoEINT4.from_weights([torch.from_numpy(w).cuda() for w in g["weights"]])     # HIP quantiser
     assert np.array_equal(mod.packed_weights.cpu().numpy(), g["packed"])
     assert np.array_equal(mod.scales.cpu().numpy(), g["scales"])
     assert np.array_equal(mod.zero_points.cpu().numpy(), g["zero_points"])
