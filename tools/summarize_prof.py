@@ -20,5 +20,5 @@ for pdir in sorted(glob.glob(os.path.join(d, "pmc_*"))):
             acc[k][row.get("Counter_Name")].append(float(row.get("Counter_Value", 0)))
         print("== pmc:", os.path.basename(pdir))
         for k, cs in acc.items():
-            if "gemm" in k or "act_quant" in k or "gemv" in k:
+            if "gemm" in k or "act_" in k or "gemv" in k:
                 print("  ", k, {c: round(sum(v) / len(v), 1) for c, v in cs.items()}, "n=", len(next(iter(cs.values()))))
