@@ -316,6 +316,8 @@ def make_moe(E, N, K, counts, seed, gap_rows=0, wscale=0.02):
     (3, 64, 96, [5, 6, 7], 0),                               # K % 256 != 0
     (2, 130, 34, [9, 4], 2),                                 # K % 32 != 0 -> generic grouped kernel
     (16, 192, 256, [0] * 15 + [50], 0),
+    (100, 64, 64, [(7 * i) % 5 for i in range(100)], 4),     # > 64 experts: multi-chunk device-side expert table
+    (70, 96, 128, [0] * 64 + [33, 0, 1, 40, 0, 2], 0),       # all the work behind the first 64-expert chunk
 ])
 @pytest.mark.parametrize("prec,tol", [("exact", EXACT_REL_FRO), ("fast", FAST_REL_FRO)])
 def test_moe_grouped_parity(fq, E, N, K, counts, gap, prec, tol):
