@@ -184,14 +184,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_i8_kernel(
             for (int l = 0; l < L; ++l) afr[s][l] = __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff[l], s * 1024, 0);
         wait_lgkmcnt0();
         __builtin_amdgcn_s_barrier();
-        v4i bcur[NF], bnx[NF], braw_nx[NF];
+        // ping-pong register sets indexed by compile-time parity (the k-step loop is fully unrolled), so the
+        // hand-over from "next" to "current" costs no register moves
+        v4i bfr2[2][NF], braw2[2][NF];
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
-            braw[j] = *reinterpret_cast<const v4i *>(lds + rB[j] + 16 * ((0 + g) ^ swB[j]));
+            braw2[0][j] = *reinterpret_cast<const v4i *>(lds + rB[j] + 16 * ((0 + g) ^ swB[j]));
             uint32_t lo0, hi0, lo1, hi1;
-            unpack8((uint32_t)braw[j][0], lo0, hi0);
-            unpack8((uint32_t)braw[j][1], lo1, hi1);
-            bcur[j][0] = (int)lo0; bcur[j][1] = (int)hi0; bcur[j][2] = (int)lo1; bcur[j][3] = (int)hi1;
+            unpack8((uint32_t)braw2[0][j][0], lo0, hi0);
+            unpack8((uint32_t)braw2[0][j][1], lo1, hi1);
+            bfr2[0][j][0] = (int)lo0; bfr2[0][j][1] = (int)hi0; bfr2[0][j][2] = (int)lo1; bfr2[0][j][3] = (int)hi1;
         }
         for (int kt = 0; kt < KT; ++kt) {
             const char *sb = lds + (kt & 1) * C::B_STAGE;
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_i8_kernel(
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int v = ks >> 1, b = ks & 1;
+                const int pc = v & 1, pn = (v + 1) & 1;          // raw-register set of this pair / the next pair
                 if (ks == 0) {
 #pragma unroll
                     for (int i = 0; i < C::CPWB; ++i) *reinterpret_cast<v4i *>(nb + wB[i]) = bst[i];
@@ -215,25 +218,25 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_i8_kernel(
                     const int nv = (v + 1) & 3;
 #pragma unroll
                     for (int j = 0; j < NF; ++j)
-                        braw_nx[j] = *reinterpret_cast<const v4i *>(src + rB[j] + 16 * ((2 * nv + g) ^ swB[j]));
+                        braw2[pn][j] = *reinterpret_cast<const v4i *>(src + rB[j] + 16 * ((2 * nv + g) ^ swB[j]));
                 }
 #pragma unroll
                 for (int l = 0; l < L; ++l)
 #pragma unroll
                     for (int j = 0; j < NF; ++j)
-                        acc[l][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bcur[j], afr[ks % D][l], acc[l][j], 0, 0, 0);
+                        acc[l][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bfr2[b][j], afr[ks % D][l], acc[l][j], 0, 0, 0);
 #pragma unroll
                 for (int j = 0; j < NF; ++j) {  // unpack for the next step under the MFMAs
                     uint32_t lo0, hi0, lo1, hi1;
                     if (b == 0) {
-                        unpack8((uint32_t)braw[j][2], lo0, hi0);
-                        unpack8((uint32_t)braw[j][3], lo1, hi1);
+                        unpack8((uint32_t)braw2[pc][j][2], lo0, hi0);
+                        unpack8((uint32_t)braw2[pc][j][3], lo1, hi1);
                     } else {
-                        unpack8((uint32_t)braw_nx[j][0], lo0, hi0);
-                        unpack8((uint32_t)braw_nx[j][1], lo1, hi1);
-                        braw[j] = braw_nx[j];
+                        unpack8((uint32_t)braw2[pn][j][0], lo0, hi0);
+                        unpack8((uint32_t)braw2[pn][j][1], lo1, hi1);
                     }
-                    bnx[j][0] = (int)lo0; bnx[j][1] = (int)hi0; bnx[j][2] = (int)lo1; bnx[j][3] = (int)hi1;
+                    bfr2[b ^ 1][j][0] = (int)lo0; bfr2[b ^ 1][j][1] = (int)hi0;
+                    bfr2[b ^ 1][j][2] = (int)lo1; bfr2[b ^ 1][j][3] = (int)hi1;
                 }
                 const int nks = ks + D;
 #pragma unroll
@@ -241,8 +244,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_i8_kernel(
                     afr[ks % D][l] = __builtin_amdgcn_raw_buffer_load_b128(
                         rsA, aoff[l], (kt + nks / KS) * a_stage + (nks % KS) * 1024, 0);
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int j = 0; j < NF; ++j) bcur[j] = bnx[j];
             }
         }
         wait_lgkmcnt0();
