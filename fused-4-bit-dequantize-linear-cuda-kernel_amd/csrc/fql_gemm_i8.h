@@ -26,8 +26,9 @@
 #pragma once
 #include "fql_common.h"
 
-template <int L, int WM, int WN, int NF, int DEPTH, int BPIPE = 0>
+template <int L, int WM, int WN, int NF, int DEPTH, int BDEPTH = 1>
 struct GemmCfg {
+    static constexpr int BD = BDEPTH;                        // weight stages in flight in the staging-register ring
     static constexpr int NW = WM * WN;
     static constexpr int THREADS = 64 * NW;
     static constexpr int BM = FQL_MB * WM;
@@ -37,7 +38,7 @@ struct GemmCfg {
     static constexpr int B_STAGE = BN * (FQL_KB / 2);        // bytes of packed weights per stage
     static constexpr int LDS_BYTES = 2 * B_STAGE;
     static constexpr int CPWB = BN / 8 / NW;                 // 1 KiB weight pieces per wave per stage
-    static_assert(NW == 8 || NW == 4, "8 waves (two per SIMD) or 4 waves (one per SIMD, 512-register budget)");
+    static_assert(NW == 8 || NW == 4 || NW == 2, "8 waves (two per SIMD), or small 4 / 2-wave workgroups for skinny tiles");
     static_assert(KS % D == 0, "ring depth must divide the steps per stage");
     static_assert((BN / 8) % NW == 0, "weight pieces must divide evenly over the waves");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -46,8 +47,8 @@ struct GemmCfg {
 __device__ __forceinline__ void wait_lgkmcnt0() { __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14)); }
 
 
-template <int L, int WM, int WN, int NF, int DEPTH, int BPIPE>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_i8_kernel(
+template <int L, int WM, int WN, int NF, int DEPTH, int BDEPTH>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     const int8_t *__restrict__ limbs, const float *__restrict__ delta,
     const int32_t *__restrict__ rowsum, const uint8_t *__restrict__ packed,
     const float *__restrict__ scales, const float *__restrict__ zps, float *__restrict__ out,
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_i8_kernel(
     int E, int T, int K, int Kp, int MBT, int N, int n_tiles, int m_slots)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub
-    using C = GemmCfg<L, WM, WN, NF, DEPTH, BPIPE>;
+    using C = GemmCfg<L, WM, WN, NF, DEPTH, BDEPTH>;
     constexpr int KS = C::KS, D = C::D;
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
@@ -158,26 +159,30 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_i8_kernel(
             for (int r = 0; r < 16; ++r) acc[l][j][r] = 0;
 
     const int KT = KB;                                       // weight stages (K padded to 256 by the pre-pass)
-    v4i bst[C::CPWB];                                        // weight pieces in flight (global -> VGPR -> LDS)
     v4i afr[D][L];                                           // A ring: D k-steps ahead
-    v4i braw[NF];
 
-    // ---- prologue: stage 0 of the weights into LDS, stage 1 into registers, A for steps 0..D-1.
-    //      Every prefetch below is UNCONDITIONAL: past the last stage the buffer offsets fall outside the
-    //      descriptors and the loads return zero.  (A load under an `if` makes hipcc's counted vmcnt
-    //      collapse to "wait for almost everything", which throws the prefetch lead away.)
+    // ---- prologue: stage 0 of the weights into LDS, stages 1..BD into the staging-register ring (slot of
+    //      stage s = s % BD), A for steps 0..D-1.  Every prefetch below is UNCONDITIONAL: past the last stage
+    //      the buffer offsets fall outside the descriptors and the loads return zero.  (A load under an `if`
+    //      makes hipcc's counted vmcnt collapse to "wait for almost everything", which throws the prefetch
+    //      lead away.)
+    constexpr int BD = C::BD;
+    v4i bst[BD][C::CPWB];                                    // weight stages in flight (global -> VGPR -> LDS)
 #pragma unroll
-    for (int i = 0; i < C::CPWB; ++i) bst[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], 0, 0);
+    for (int i = 0; i < C::CPWB; ++i) bst[0][i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], 0, 0);
 #pragma unroll
-    for (int i = 0; i < C::CPWB; ++i) *reinterpret_cast<v4i *>(lds + wB[i]) = bst[i];
+    for (int i = 0; i < C::CPWB; ++i) *reinterpret_cast<v4i *>(lds + wB[i]) = bst[0][i];
 #pragma unroll
-    for (int i = 0; i < C::CPWB; ++i) bst[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], FQL_KB / 2, 0);
+    for (int s = 1; s <= BD; ++s)
+#pragma unroll
+        for (int i = 0; i < C::CPWB; ++i)
+            bst[s % BD][i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], s * (FQL_KB / 2), 0);
 
-    if (active && BPIPE) {
-        // ---- variant with the weight fragments software-pipelined one k-step ahead: the ds_reads of the
-        //      next 64-k pair and the nibble unpack of the next step are issued under the current step's
-        //      MFMAs.  One barrier per stage, placed at step 5: by then every wave has parked stage kt+1 (its
-        //      step 0) and has finished reading stage kt (the last read of it is issued at step 4).
+    if (active) {
+        // ---- the weight fragments are software-pipelined one k-step ahead: the ds_reads of the next 64-k
+        //      pair and the nibble unpack of the next step are issued under the current step's MFMAs.  One
+        //      barrier per stage, placed at step 5: by then every wave has parked stage kt+1 (its step 0) and
+        //      has finished reading stage kt (the last read of it is issued at step 4).
 #pragma unroll
         for (int s = 0; s < D; ++s)
 #pragma unroll
@@ -195,7 +200,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_i8_kernel(
             unpack8((uint32_t)braw2[0][j][1], lo1, hi1);
             bfr2[0][j][0] = (int)lo0; bfr2[0][j][1] = (int)hi0; bfr2[0][j][2] = (int)lo1; bfr2[0][j][3] = (int)hi1;
         }
-        for (int kt = 0; kt < KT; ++kt) {
+        for (int kt0 = 0; kt0 < KT; kt0 += BD) {
+#pragma unroll
+          for (int kk = 0; kk < BD; ++kk) {                  // unrolled so the staging-ring slot is static
+            const int kt = kt0 + kk;
+            if (kt >= KT) break;
             const char *sb = lds + (kt & 1) * C::B_STAGE;
             char *nb = lds + ((kt + 1) & 1) * C::B_STAGE;
 #pragma unroll
@@ -203,11 +212,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_i8_kernel(
                 const int v = ks >> 1, b = ks & 1;
                 const int pc = v & 1, pn = (v + 1) & 1;          // raw-register set of this pair / the next pair
                 if (ks == 0) {
-#pragma unroll
-                    for (int i = 0; i < C::CPWB; ++i) *reinterpret_cast<v4i *>(nb + wB[i]) = bst[i];
+                    // the other LDS stage was released by the barrier of stage kt-1: park stage kt+1 there now,
+                    // then refill that ring slot with stage kt+1+BD (BD stages of HBM lead).
+                #pragma unroll
+                    for (int i = 0; i < C::CPWB; ++i) *reinterpret_cast<v4i *>(nb + wB[i]) = bst[(kk + 1) % BD][i];
 #pragma unroll
                     for (int i = 0; i < C::CPWB; ++i)
-                        bst[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], (kt + 2) * (FQL_KB / 2), 0);
+                        bst[(kk + 1) % BD][i] =
+                            __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], (kt + 1 + BD) * (FQL_KB / 2), 0);
                 }
                 if (ks == 5) {
                     wait_lgkmcnt0();
@@ -220,11 +232,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_i8_kernel(
                     for (int j = 0; j < NF; ++j)
                         braw2[pn][j] = *reinterpret_cast<const v4i *>(src + rB[j] + 16 * ((2 * nv + g) ^ swB[j]));
                 }
+#if defined(FQL_ABLATE) && FQL_ABLATE == 1
+#pragma unroll
+                for (int l = 0; l < L; ++l) asm volatile("" ::"v"(afr[ks % D][l]));
+#pragma unroll
+                for (int j = 0; j < NF; ++j) asm volatile("" ::"v"(bfr2[b][j]));
+#else
 #pragma unroll
                 for (int l = 0; l < L; ++l)
 #pragma unroll
                     for (int j = 0; j < NF; ++j)
                         acc[l][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bfr2[b][j], afr[ks % D][l], acc[l][j], 0, 0, 0);
+#endif
 #pragma unroll
                 for (int j = 0; j < NF; ++j) {  // unpack for the next step under the MFMAs
                     uint32_t lo0, hi0, lo1, hi1;
@@ -238,97 +257,38 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_i8_kernel(
                     bfr2[b ^ 1][j][0] = (int)lo0; bfr2[b ^ 1][j][1] = (int)hi0;
                     bfr2[b ^ 1][j][2] = (int)lo1; bfr2[b ^ 1][j][3] = (int)hi1;
                 }
-                const int nks = ks + D;
-#pragma unroll
-                for (int l = 0; l < L; ++l)
-                    afr[ks % D][l] = __builtin_amdgcn_raw_buffer_load_b128(
-                        rsA, aoff[l], (kt + nks / KS) * a_stage + (nks % KS) * 1024, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        wait_lgkmcnt0();
-    } else if (active) {
-#pragma unroll
-        for (int s = 0; s < D; ++s)
-#pragma unroll
-            for (int l = 0; l < L; ++l) afr[s][l] = __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff[l], s * 1024, 0);
-        wait_lgkmcnt0();
-        __builtin_amdgcn_s_barrier();
-        for (int kt = 0; kt < KT; ++kt) {
-            const char *sb = lds + (kt & 1) * C::B_STAGE;
-            char *nb = lds + ((kt + 1) & 1) * C::B_STAGE;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-#if !defined(FQL_ABL_NOB)
-                if (ks == 0) {
-                    // the other LDS stage was released by the barrier that ended stage kt-1: park stage kt+1
-                    // there now, then refill the staging registers with stage kt+2 (a full stage of lead).
-#pragma unroll
-                    for (int i = 0; i < C::CPWB; ++i) *reinterpret_cast<v4i *>(nb + wB[i]) = bst[i];
-#pragma unroll
-                    for (int i = 0; i < C::CPWB; ++i)
-                        bst[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], (kt + 2) * (FQL_KB / 2), 0);
-                }
-#endif
-                const int v = ks >> 1, b = ks & 1;
-#if defined(FQL_ABL_NOBREAD)
-                if (kt == 0 && ks == 0)
-#else
-                if (b == 0)
-#endif
-                {
-#pragma unroll
-                    for (int j = 0; j < NF; ++j)
-                        braw[j] = *reinterpret_cast<const v4i *>(sb + rB[j] + 16 * ((2 * v + g) ^ swB[j]));
-                }
-                v4i bfr[NF];
-#pragma unroll
-                for (int j = 0; j < NF; ++j) {
-                    uint32_t lo0, hi0, lo1, hi1;
-                    unpack8((uint32_t)braw[j][2 * b], lo0, hi0);
-                    unpack8((uint32_t)braw[j][2 * b + 1], lo1, hi1);
-                    bfr[j][0] = (int)lo0; bfr[j][1] = (int)hi0; bfr[j][2] = (int)lo1; bfr[j][3] = (int)hi1;
-                }
-#if defined(FQL_ABLATE) && FQL_ABLATE == 1
-#pragma unroll
-                for (int l = 0; l < L; ++l) asm volatile("" ::"v"(afr[ks % D][l]));
-#pragma unroll
-                for (int j = 0; j < NF; ++j) asm volatile("" ::"v"(bfr[j]));
-#else
-#pragma unroll
-                for (int l = 0; l < L; ++l)
-#pragma unroll
-                    for (int j = 0; j < NF; ++j)
-                        acc[l][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bfr[j], afr[ks % D][l], acc[l][j], 0, 0, 0);
-#endif
                 // refill the ring slot just consumed with the A fragments D steps ahead
                 const int nks = ks + D;
-#if !defined(FQL_ABLATE) || FQL_ABLATE != 3
 #pragma unroll
                 for (int l = 0; l < L; ++l)
                     afr[ks % D][l] = __builtin_amdgcn_raw_buffer_load_b128(
                         rsA, aoff[l], (kt + nks / KS) * a_stage + (nks % KS) * 1024, 0);
-#endif
                 // pin the software pipeline: without this the machine scheduler sinks the prefetch loads
                 // down to their use D steps later (load; s_waitcnt vmcnt(0); mfma) to save registers.
                 __builtin_amdgcn_sched_barrier(0);
             }
-            wait_lgkmcnt0();                   // my LDS writes of stage kt+1 are done, my reads of stage kt too
-            __builtin_amdgcn_s_barrier();
+          }
         }
+        wait_lgkmcnt0();
     } else {
         // waves past the expert's last row: only help stage the weights and keep the barriers in step
         wait_lgkmcnt0();
         __builtin_amdgcn_s_barrier();
-        for (int kt = 0; kt < KT; ++kt) {
+        for (int kt0 = 0; kt0 < KT; kt0 += BD) {
+#pragma unroll
+          for (int kk = 0; kk < BD; ++kk) {
+            const int kt = kt0 + kk;
+            if (kt >= KT) break;
             char *nb = lds + ((kt + 1) & 1) * C::B_STAGE;
 #pragma unroll
-            for (int i = 0; i < C::CPWB; ++i) *reinterpret_cast<v4i *>(nb + wB[i]) = bst[i];
+            for (int i = 0; i < C::CPWB; ++i) *reinterpret_cast<v4i *>(nb + wB[i]) = bst[(kk + 1) % BD][i];
 #pragma unroll
             for (int i = 0; i < C::CPWB; ++i)
-                bst[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], (kt + 2) * (FQL_KB / 2), 0);
+                bst[(kk + 1) % BD][i] =
+                    __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], (kt + 1 + BD) * (FQL_KB / 2), 0);
             wait_lgkmcnt0();
             __builtin_amdgcn_s_barrier();
+          }
         }
         continue;
     }

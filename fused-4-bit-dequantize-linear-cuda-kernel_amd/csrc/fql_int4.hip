@@ -51,19 +51,19 @@ inline Workspace carve(void *base, int L, int T, int E, int Kp)
 
 // ---- MFMA tile configurations (see fql_gemm_i8.h): 8 waves as WM x WN, NF 32-column fragments per wave.
 struct TileShape { int bm, bn; };
+// X(id, WM, WN, NF, A-ring depth in k-steps, weight stages in flight)
 #define FQL_CFG_LIST(X)        \
-    X(0, 4, 2, 3, 4, 0)        /* 128 x 192, A ring 4 steps */ \
-    X(1, 4, 2, 2, 4, 0)        /* 128 x 128 */ \
-    X(2, 4, 2, 4, 2, 0)        /* 128 x 256 (2-limb register budget) */ \
-    X(3, 2, 4, 2, 4, 0)        /*  64 x 256 */ \
-    X(4, 2, 4, 1, 4, 0)        /*  64 x 128 */ \
-    X(5, 1, 8, 1, 4, 0)        /*  32 x 256 */ \
-    X(6, 4, 2, 3, 2, 0)        /* 128 x 192, A ring 2 steps */ \
-    X(7, 4, 2, 3, 2, 1)        /* 128 x 192, A ring 2 steps, weight fragments pipelined one step ahead */ \
-    X(8, 4, 2, 2, 4, 1)        /* 128 x 128, pipelined */ \
-    X(9, 4, 2, 3, 4, 1)        /* 128 x 192, A ring 4 steps, pipelined (2-limb register budget) */ \
-    X(10, 2, 4, 2, 4, 1)       /*  64 x 256, pipelined */
-constexpr int FQL_NUM_CFG = 11;
+    X(0, 4, 2, 3, 2, 1)        /* 128 x 192 (3 limbs: 2-step A ring is what the register budget allows) */ \
+    X(1, 4, 2, 2, 4, 1)        /* 128 x 128 */ \
+    X(2, 4, 2, 4, 2, 1)        /* 128 x 256 (2-limb register budget) */ \
+    X(3, 4, 2, 3, 4, 1)        /* 128 x 192, 4-step A ring (2-limb register budget) */ \
+    X(4, 2, 4, 2, 4, 1)        /*  64 x 256 */ \
+    X(5, 1, 8, 1, 4, 1)        /*  32 x 256 */ \
+    X(6, 4, 1, 2, 8, 4)        /* 128 x  64, 4 waves: skinny tiles for few rows (HBM-bound: many small */ \
+    X(7, 2, 2, 1, 8, 4)        /*  64 x  64, 4 waves   workgroups per CU, 4 weight stages in flight, deep */ \
+    X(8, 1, 2, 1, 8, 4)        /*  32 x  64, 2 waves   A ring to cover L2 latency) */ \
+    X(9, 4, 2, 3, 2, 2)        /* 128 x 192, 2 weight stages in flight */
+constexpr int FQL_NUM_CFG = 10;
 
 // The MFMA path addresses its operands through 32-bit buffer offsets.
 inline bool mfma_addressable(int L, int T, int E, int K, int N)
@@ -106,13 +106,13 @@ int launch_act_quant(const float *x, const int32_t *gather, int n_src, const Wor
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
-template <int L, int WM, int WN, int NF, int DEPTH, int BPIPE>
+template <int L, int WM, int WN, int NF, int DEPTH, int BDEPTH>
 int launch_gemm_cfg(const Workspace &w, const uint8_t *packed, const float *scales, const float *zps,
                     float *out, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT, int N,
                     hipStream_t st)
 {
-    using C = GemmCfg<L, WM, WN, NF, DEPTH, BPIPE>;
-    auto kern = gemm_i8_kernel<L, WM, WN, NF, DEPTH, BPIPE>;
+    using C = GemmCfg<L, WM, WN, NF, DEPTH, BDEPTH>;
+    auto kern = gemm_i8_kernel<L, WM, WN, NF, DEPTH, BDEPTH>;
     static bool attr_set = false;           // idempotent; a race only repeats the same call
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -124,7 +124,8 @@ int launch_gemm_cfg(const Workspace &w, const uint8_t *packed, const float *scal
     const int m_slots = (tpe == nullptr) ? (T + C::BM - 1) / C::BM : T / C::BM + E;
     long long blocks = (long long)n_tiles * m_slots;        // worst-case tile count (real count is on the device)
     if (blocks <= 0 || blocks > 0x7fffffffLL) return FQL_ERR_BAD_SHAPE;
-    const int cus = compute_units();                         // persistent: one workgroup per CU walks the tiles
+    // persistent: the 8-wave workgroups fill a CU alone; the small skinny-tile workgroups share it 4 / 8 ways
+    const int cus = compute_units() * (C::NW >= 8 ? 1 : (C::NW == 4 ? 2 : 4));      // 2 waves per SIMD either way
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, w.limbs, w.delta, w.rowsum,
                        packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots);
@@ -156,13 +157,21 @@ inline int choose_cfg(int L, int E, int T, int K, int N, bool grouped)
     (void)K;
     const int groups = grouped ? (E > 0 ? E : 1) : 1;
     const int m = (T + groups - 1) / groups;                 // rows per group if evenly routed
+    // few rows in total: the op is HBM-bound, what matters is enough tiles to have every CU streaming
+    // weights (N / 64 tiles per row block instead of N / 256)
+    const long long wide_tiles = (long long)groups * ((m + 127) / 128) * ((N + 255) / 256);
+    if (wide_tiles < 128 && m <= 128) {
+        if (m <= 32) return 8;                               //  32 x 64, 2 waves
+        if (m <= 64) return 7;                               //  64 x 64, 4 waves
+        return 6;                                            // 128 x 64, 4 waves
+    }
     if (m <= 32) return 5;                                   //  32 x 256
-    if (m <= 64) return 10;                                  //  64 x 256, weight fragments pipelined
+    if (m <= 64) return 4;                                   //  64 x 256
     const int mt = groups * ((m + 127) / 128);
     struct Cand { int cfg, bn; };
     // 3 limbs: 128 x 192 with a 2-step A ring (register budget) / 128 x 128; 2 limbs: 4-step ring, + 128 x 256
-    const Cand c3[2] = {{7, 192}, {8, 128}};
-    const Cand c2[3] = {{9, 192}, {8, 128}, {2, 256}};
+    const Cand c3[2] = {{0, 192}, {1, 128}};
+    const Cand c2[3] = {{3, 192}, {1, 128}, {2, 256}};
     const Cand *cands = (L == 2) ? c2 : c3;
     const int nc = (L == 2) ? 3 : 2;
     int best = cands[0].cfg;

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Time QuantizedLinear 4096->11008 (or --k/--n) over a sweep of batch sizes (product call, hipGraph of 20 launches)."""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import fused_int4_amd as fq
+from fused_int4_amd import ops
+ap = argparse.ArgumentParser()
+ap.add_argument("--k", type=int, default=4096); ap.add_argument("--n", type=int, default=11008)
+ap.add_argument("--batches", default="1,2,4,5,8,16,32,64,128,256,512,1024")
+ap.add_argument("--precision", default="exact")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(0)
+sets = [fq.quantize_weights(torch.randn(a.n, a.k, device=dev, generator=g) * 0.02) for _ in range(8)]
+wbytes = a.n * a.k // 2
+for B in [int(b) for b in a.batches.split(",")]:
+    x = torch.randn(B, a.k, device=dev, generator=g)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for s in sets[:2]:
+            ops.linear_forward(x, *s, precision=a.precision)
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=st):
+            for i in range(16):
+                ops.linear_forward(x, *sets[i % len(sets)], precision=a.precision)
+        gr.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(5):
+            gr.replay()
+        e1.record(st)
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 80 * 1e3
+    print(f"B={B:5d}: {us:8.1f} us/call   {wbytes/us/1e6:7.2f} TB/s packed-weight   {2.0*B*a.k*a.n/us/1e6:8.1f} TFLOP/s")
