@@ -17,8 +17,7 @@
 //   is (0,2,4,6,1,3,5,7), the order the in-register nibble unpack (unpack8) produces.
 //   Columns K..Kp-1 are zero.
 //
-// HBM-bound: reads T*K*4 bytes twice (the second read hits L2 / Infinity Cache), writes L*T*Kp bytes
-// in contiguous 8 KiB blocks.  Two launches: per-row scale, then the tiled conversion.
+// HBM-bound: reads T*K*4 bytes once, writes L*T*Kp bytes as full 128-byte lines.  One launch.
 #pragma once
 #include "fql_common.h"
 #include <math.h>
@@ -51,223 +50,207 @@ __device__ __forceinline__ int act_exponent(float m)
     return e;
 }
 
-// ---- kernel 1: per-row scale.  One 256-thread workgroup per row (all loads independent and in
-//      flight together): delta[t] = 2^e (NaN for a non-finite row) and the per-limb digit sums rowsum[l][t];
-//      for the MoE entry point also zero-fills the rows of `out` that no expert covers (reference
-//      semantics: torch::zeros, csrc/moe_int4_kernel.cu:109).
-template <int L>
-__global__ __launch_bounds__(256) void act_scale_kernel(
+// ---- single-launch pre-pass.  One 256-thread workgroup owns ACT_ROWS = 8 consecutive padded rows end to end:
+//      thread t holds row r = t & 7 and the 16-float chunks ch = (t >> 3) + 32 j of that row (K <= 4096: the
+//      workgroup's whole 128 KiB of x sits in registers, read from HBM exactly once, all loads in flight
+//      together).  Row max -> 3 xor-shuffles + 4-wave LDS combine -> delta; then every 16-float chunk becomes
+//      one 16-byte limb chunk per limb: k = 16 ch of the row IS lane group g / k-step ks of the fragment layout
+//      (see the header comment), and the 8 rows of a workgroup are 8 neighbouring lanes of the fragment, so
+//      each group of 8 threads stores one full 128-byte line.  No LDS staging of data, no second launch.
+//      Limb row sums by v_dot4 against 0x01010101, reduced the same way as the max.
+//      Rows longer than 4096 are processed in 4096-k slabs: pass 1 streams all slabs for the max, pass 2
+//      re-reads them (L2 hits: the workgroup just read them).
+//      Workgroups with blockIdx.x >= rblocks (MoE entry point only) zero-fill the rows of `out` no expert
+//      covers (reference semantics: torch::zeros, csrc/moe_int4_kernel.cu:109).
+#define ACT_ROWS 8
+#define ACT_CH 8              // chunks per thread per slab: 32 chunk columns x 8 = 256 chunks = 4096 k
+
+template <int L, bool VEC>
+__global__ __launch_bounds__(256) void act_fused_kernel(
     const float *__restrict__ x, const int32_t *__restrict__ gather, int n_src, float *__restrict__ delta,
-    int32_t *__restrict__ rowsum, int T, int K,
+    int32_t *__restrict__ rowsum, int8_t *__restrict__ limbs, int T, int K, int KB, int MBT, int rblocks,
     float *__restrict__ out, int N, const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs, int E)
 {
-    __shared__ float s_red[4];
-    __shared__ int s_bad[4];
+    __shared__ int s_tok[ACT_ROWS];
+    __shared__ uint32_t s_max[4][ACT_ROWS];
+    __shared__ int s_sum[4][ACT_ROWS][L];
+    __shared__ int s_lo[64], s_cnt[64], s_pad[64], s_total;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t = blockIdx.x;
-    if (tpe != nullptr) {
+
+    if ((int)blockIdx.x >= rblocks) {             // ---- coverage workgroups: 256 rows of `out` each
+        const int t = ((int)blockIdx.x - rblocks) * 256 + tid;
         bool covered = false;
         int cp = 0, ct = 0;
         for (int base = 0; base < E; base += 64) {
             const ExpertLane xl = expert_chunk(tpe, offs, E, T, FQL_MB, base, lane, cp, ct);
-            covered |= __ballot(t >= xl.lo && t < xl.lo + xl.cnt) != 0ull;
-        }
-        if (!covered) {
-            if (out != nullptr) {
-                float *orow = out + (size_t)t * N;
-                for (int i = tid; i < N; i += 256) orow[i] = 0.0f;
+            const int ne = (E - base) < 64 ? (E - base) : 64;
+            for (int i = 0; i < ne; ++i) {
+                const int lo = __shfl(xl.lo, i, 64), cnt = __shfl(xl.cnt, i, 64);
+                covered |= (t >= lo && t < lo + cnt);
             }
-            return;
         }
+        if (t < T && !covered) {
+            float *orow = out + (size_t)t * N;
+            for (int i = 0; i < N; ++i) orow[i] = 0.0f;      // rare path: rows no expert owns
+        }
+        return;
     }
-    const float *xr = x + (size_t)source_row(gather, n_src, t) * K;
-    const bool vec_ok = ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-    float m = 0.0f;
-    int bad = 0;
-    if (vec_ok) {
-        const v4f *xv = reinterpret_cast<const v4f *>(xr);
-        const int nv = K >> 2;
-        for (int i0 = 0; i0 < nv; i0 += 1024) {               // 4 independent 16-byte loads per thread per trip
-            v4f v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 256 + tid;
-                v[u] = (i < nv) ? xv[i] : v4f{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float a = fabsf(v[u][j]);
-                    bad |= !(a <= 3.402823466e+38f);
-                    m = fmaxf(m, a);
-                }
-        }
-    } else {
-        for (int i = tid; i < K; i += 256) {
-            const float a = fabsf(xr[i]);
-            bad |= !(a <= 3.402823466e+38f);
-            m = fmaxf(m, a);
-        }
-    }
-    m = wave_max(m);
-    bad = __any(bad) ? 1 : 0;
-    if (lane == 0) { s_red[wave] = m; s_bad[wave] = bad; }
-    __syncthreads();
-    m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-    bad = s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3];
-    const int e = act_exponent<L>(bad ? 0.0f : m);
-    const float inv = bad ? 0.0f : ldexpf(1.0f, -e);
 
-    // second pass over the row (L1 / L2 hits): the per-limb digit sums, so kernel 2 needs no atomics
-    int sums[L];
-#pragma unroll
-    for (int l = 0; l < L; ++l) sums[l] = 0;
-    auto add = [&](float v) {
-        int X = (int)rintf(v * inv);
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-            int d;
-            if (l == L - 1) d = X;
-            else { d = ((X + 128) & 255) - 128; X = (X - d) >> 8; }
-            sums[l] += d;
-        }
-    };
-    if (vec_ok) {
-        const v4f *xv = reinterpret_cast<const v4f *>(xr);
-        const int nv = K >> 2;
-        for (int i0 = 0; i0 < nv; i0 += 1024) {
-            v4f v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 256 + tid;
-                v[u] = (i < nv) ? xv[i] : v4f{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) add(v[u][j]);
-        }
-    } else {
-        for (int i = tid; i < K; i += 256) add(xr[i]);
-    }
-    __shared__ int s_sum[4 * L];
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-        const int sv = wave_sum_i(sums[l]);
-        if (lane == 0) s_sum[wave * L + l] = sv;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        delta[t] = bad ? __builtin_nanf("") : ldexpf(1.0f, e);
-#pragma unroll
-        for (int l = 0; l < L; ++l)
-            rowsum[(size_t)l * T + t] = s_sum[l] + s_sum[L + l] + s_sum[2 * L + l] + s_sum[3 * L + l];
-    }
-}
-
-// ---- kernel 2: one workgroup per (32-row block mb, 256-k block kb).  Coalesced float4 reads of the
-//      32 x 256 tile (all 8 loads of a thread issued before any is used), quantise to L limbs, scatter the
-//      bytes into the fragment image in LDS, then stream the L contiguous 8 KiB fragment blocks out with
-//      16-byte stores.
-template <int L>
-__global__ __launch_bounds__(256) void act_limbs_kernel(
-    const float *__restrict__ x, const int32_t *__restrict__ gather, int n_src,
-    const float *__restrict__ delta, int8_t *__restrict__ limbs, int T, int K, int KB, int MBT,
-    const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs, int E)
-{
-    __shared__ __attribute__((aligned(16))) char img[L * 8192];
-    __shared__ int s_tok[FQL_MB];
-    const int mb = blockIdx.x, kb = blockIdx.y;
-    const int tid = threadIdx.x;
-    const int gi = tid & 31;                      // 8-group inside the 256-k block
-    const bool vec_ok = ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-
-    // token row of each of the block's 32 padded rows (-1: padding)
+    // ---- token row of each of the workgroup's padded rows (-1: padding); total = padded rows in use
+    const int p0 = blockIdx.x * ACT_ROWS;
+    int total;
     if (tpe == nullptr) {
-        if (tid < FQL_MB) s_tok[tid] = (mb * FQL_MB + tid < T) ? mb * FQL_MB + tid : -1;
+        if (tid < ACT_ROWS) s_tok[tid] = (p0 + tid < T) ? p0 + tid : -1;
+        total = (T + FQL_MB - 1) / FQL_MB * FQL_MB;
     } else {
-        // wave 0 publishes the expert table chunk by chunk; 32 threads then look their row up in parallel
-        __shared__ int s_lo[64], s_cnt[64], s_pad[64];
         int t_found = -1;
         int cp = 0, ct = 0;
         for (int base = 0; base < E; base += 64) {
             if (tid < 64) {
                 const ExpertLane xl = expert_chunk(tpe, offs, E, T, FQL_MB, base, tid, cp, ct);
                 s_lo[tid] = xl.lo; s_cnt[tid] = xl.cnt; s_pad[tid] = xl.pad_excl;
+                if (tid == 0) s_total = cp;               // running padded-row total
             }
             __syncthreads();
-            if (tid < FQL_MB && t_found < 0) {
-                const int p = mb * FQL_MB + tid;
+            if (tid < ACT_ROWS && t_found < 0) {
+                const int p = p0 + tid;
                 const int ne = (E - base) < 64 ? (E - base) : 64;
                 for (int i = 0; i < ne; ++i) {
                     const int rel = p - s_pad[i];
                     if (rel >= 0 && rel < s_cnt[i]) { t_found = s_lo[i] + rel; break; }
                 }
             }
+            total = s_total;
             __syncthreads();
         }
-        if (tid < FQL_MB) s_tok[tid] = t_found;
+        if (tid < ACT_ROWS) s_tok[tid] = t_found;
     }
+    if (p0 >= total) return;                      // past the last expert's rows (uniform per workgroup)
     __syncthreads();
 
-    const int k0 = kb * FQL_KB + gi * 8;
-    int tok[4];
-    float inv[4];
-    v4f va[4], vb[4];
+    const int r = tid & 7, col = tid >> 3;        // row of the workgroup, chunk column 0..31
+    const int tok = s_tok[r];
+    const int p = p0 + r, mb = p >> 5, r32 = p & 31;
+    const float *xr = x + (size_t)(tok >= 0 ? source_row(gather, n_src, tok) : 0) * K;
+    const int nch = KB * 16;                      // 16-float chunks per padded row
+    const int slabs = (nch + 32 * ACT_CH - 1) / (32 * ACT_CH);
+
+    // VEC (K % 16 == 0, x 16-byte aligned; host-checked): every load is unconditional.  A chunk past K (the
+    // zero padding up to a multiple of 256) or a padding row re-reads valid data -- duplicates do not move the
+    // row max -- and is masked to +0.0f in pass 2.
+    v4f xv[ACT_CH][4];
+    auto chunk_ok = [&](int slab, int j) { return tok >= 0 && (slab * 32 * ACT_CH + col + 32 * j) * 16 < K; };
+    auto load_slab = [&](int slab) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        tok[j] = s_tok[(tid >> 5) + 8 * j];
-        va[j] = vb[j] = v4f{0.f, 0.f, 0.f, 0.f};
-        inv[j] = 0.0f;
-        if (tok[j] >= 0) {
-            const float *xr = x + (size_t)source_row(gather, n_src, tok[j]) * K;
-            if (vec_ok && k0 + 8 <= K) {
-                va[j] = *reinterpret_cast<const v4f *>(xr + k0);
-                vb[j] = *reinterpret_cast<const v4f *>(xr + k0 + 4);
+        for (int j = 0; j < ACT_CH; ++j) {
+            const int k0 = (slab * 32 * ACT_CH + col + 32 * j) * 16;
+            if (VEC) {
+                const float *src = xr + (k0 < K ? k0 : 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xv[j][q] = *reinterpret_cast<const v4f *>(src + 4 * q);
             } else {
 #pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        xv[j][q][i] = (k0 + 4 * q + i < K) ? xr[k0 + 4 * q + i] : 0.0f;
+            }
+        }
+    };
+
+    // ---- pass 1: row maximum, on the bit patterns: |x| as an unsigned integer orders finite < Inf < NaN, so one
+    //      integer max finds the magnitude and flags a non-finite row
+    uint32_t mu = 0u;
+    for (int slab = 0; slab < slabs; ++slab) {
+        load_slab(slab);
+#pragma unroll
+        for (int j = 0; j < ACT_CH; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    va[j][i] = (k0 + i < K) ? xr[k0 + i] : 0.0f;
-                    vb[j][i] = (k0 + 4 + i < K) ? xr[k0 + 4 + i] : 0.0f;
+                    const uint32_t u = __float_as_uint(xv[j][q][i]) & 0x7FFFFFFFu;
+                    mu = u > mu ? u : mu;
+                }
+    }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+        const uint32_t n = (uint32_t)__shfl_xor((int)mu, o, 64);
+        mu = n > mu ? n : mu;
+    }
+    if (lane < ACT_ROWS) s_max[wave][lane] = mu;
+    __syncthreads();
+    {
+        const uint32_t a = s_max[0][r] > s_max[1][r] ? s_max[0][r] : s_max[1][r];
+        const uint32_t b = s_max[2][r] > s_max[3][r] ? s_max[2][r] : s_max[3][r];
+        mu = a > b ? a : b;
+    }
+    const bool bad = mu >= 0x7F800000u;
+    const float m = __uint_as_float(mu);
+    const int e = act_exponent<L>(bad ? 0.0f : m);
+    const float inv = bad ? 0.0f : ldexpf(1.0f, -e);           // non-finite row: limbs 0, delta NaN -> outputs NaN
+    if (tid < ACT_ROWS && tok >= 0) delta[tok] = bad ? __builtin_nanf("") : ldexpf(1.0f, e);
+
+    // ---- pass 2: quantise and store
+    int sums[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) sums[l] = 0;
+    for (int slab = 0; slab < slabs; ++slab) {
+        if (slabs > 1) load_slab(slab);
+#pragma unroll
+        for (int j = 0; j < ACT_CH; ++j) {
+            const int ch = slab * 32 * ACT_CH + col + 32 * j;
+            if (ch >= nch) continue;
+            // All L balanced digits of X at once: Y = X + sum_{l<L-1} 128*256^l has plain base-256 digits
+            // d_l + 128 in its low bytes and the top digit above them, so byte l of Z = Y ^ 0x..8080 is limb l.
+            constexpr int BIAS = (L == 3) ? 0x8080 : (L == 2) ? 0x80 : 0;
+            const uint32_t keep = chunk_ok(slab, j) ? 0xFFFFFFFFu : 0u;   // padding: +0.0f whatever was re-read
+            uint32_t Z[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float xq = __uint_as_float(__float_as_uint(xv[j][q][i]) & keep) * inv;
+                    Z[4 * q + i] = (uint32_t)((int)rintf(xq) + BIAS) ^ (uint32_t)BIAS;
+                }
+            // byte transpose into the limb dwords; inside an 8-group the byte order is (0,2,4,6,1,3,5,7):
+            // dword 2h = k (0,2,4,6) of 8-group h, dword 2h+1 = k (1,3,5,7)
+            uint32_t w[L][4];
+#pragma unroll
+            for (int dw = 0; dw < 4; ++dw) {
+                const int kbase = 8 * (dw >> 1) + (dw & 1);
+                const uint32_t za = Z[kbase], zb = Z[kbase + 2], zc = Z[kbase + 4], zd = Z[kbase + 6];
+                const uint32_t lo_ab = __builtin_amdgcn_perm(zb, za, 0x05010400u);      // a0 b0 a1 b1
+                const uint32_t lo_cd = __builtin_amdgcn_perm(zd, zc, 0x05010400u);
+                w[0][dw] = __builtin_amdgcn_perm(lo_cd, lo_ab, 0x05040100u);            // a0 b0 c0 d0
+                if (L > 1) w[1 % L][dw] = __builtin_amdgcn_perm(lo_cd, lo_ab, 0x07060302u);   // a1 b1 c1 d1
+                if (L > 2) {
+                    const uint32_t hi_ab = __builtin_amdgcn_perm(zb, za, 0x07030602u);  // a2 b2 a3 b3
+                    const uint32_t hi_cd = __builtin_amdgcn_perm(zd, zc, 0x07030602u);
+                    w[2 % L][dw] = __builtin_amdgcn_perm(hi_cd, hi_ab, 0x05040100u);    // a2 b2 c2 d2
                 }
             }
-            const float d = delta[tok[j]];
-            inv[j] = (d == d) ? 1.0f / d : 0.0f;  // delta is a power of two: exact reciprocal; NaN row -> limbs 0
-        }
-    }
-    // fragment position of this 8-group: chunk c = gi / 4 -> (v = c >> 1, g = c & 1), half b, byte 8*(gi & 1)
-    const int c = gi >> 2, b = (gi >> 1) & 1;
-    const int ks = 2 * (c >> 1) + b, g = c & 1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = (tid >> 5) + 8 * j;
-        const float v[8] = {va[j][0], va[j][1], va[j][2], va[j][3], vb[j][0], vb[j][1], vb[j][2], vb[j][3]};
-        uint32_t w[L][2];
-#pragma unroll
-        for (int l = 0; l < L; ++l) w[l][0] = w[l][1] = 0u;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int X = (int)rintf(v[i] * inv[j]);
-            const int pos = (i >> 1) + ((i & 1) << 2);           // (0,2,4,6,1,3,5,7) -> 0..7
+            const int kb = ch >> 4, c16 = ch & 15;    // k = 32 (2v+g) + 16 b  ->  c16 = 2 (2v+g) + b
+            const int ks = 2 * (c16 >> 2) + (c16 & 1), g = (c16 >> 1) & 1;
 #pragma unroll
             for (int l = 0; l < L; ++l) {
-                int d;
-                if (l == L - 1) d = X;                            // top limb: remaining value, in range by construction
-                else { d = ((X + 128) & 255) - 128; X = (X - d) >> 8; }
-                w[l][pos >> 2] |= (uint32_t)(d & 255) << ((pos & 3) * 8);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sums[l] = __builtin_amdgcn_sdot4((int)w[l][i], 0x01010101, sums[l], false);
+                int8_t *dst = limbs + (((size_t)l * KB + kb) * MBT + mb) * 8192 + ((ks * 64) + g * 32 + r32) * 16;
+                *reinterpret_cast<v4i *>(dst) = v4i{(int)w[l][0], (int)w[l][1], (int)w[l][2], (int)w[l][3]};
             }
         }
-        const int off = ((ks * 64) + g * 32 + r) * 16 + ((gi & 1) << 3);
-#pragma unroll
-        for (int l = 0; l < L; ++l) *reinterpret_cast<uint2 *>(img + l * 8192 + off) = make_uint2(w[l][0], w[l][1]);
     }
-    __syncthreads();
 #pragma unroll
     for (int l = 0; l < L; ++l) {
-        int8_t *dst = limbs + (((size_t)l * KB + kb) * MBT + mb) * 8192;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<v4i *>(dst + (i * 256 + tid) * 16) = *reinterpret_cast<const v4i *>(img + l * 8192 + (i * 256 + tid) * 16);
+        for (int o = 8; o < 64; o <<= 1) sums[l] += __shfl_xor(sums[l], o, 64);
+        if (lane < ACT_ROWS) s_sum[wave][lane][l] = sums[l];
+    }
+    __syncthreads();
+    if (tid < ACT_ROWS && tok >= 0) {
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+            rowsum[(size_t)l * T + tok] = (s_sum[0][tid][l] + s_sum[1][tid][l]) + (s_sum[2][tid][l] + s_sum[3][tid][l]);
     }
 }

@@ -96,13 +96,15 @@ template <int L>
 int launch_act_quant(const float *x, const int32_t *gather, int n_src, const Workspace &w, int T, int K, int Kp,
                      int MBT, float *out, int N, const int32_t *tpe, const int32_t *offs, int E, hipStream_t st)
 {
-    hipLaunchKernelGGL((act_scale_kernel<L>), dim3(T), dim3(256), 0, st, x, gather, n_src, w.delta, w.rowsum, T, K,
-                       out, N, tpe, offs, E);
-    if (hipGetLastError() != hipSuccess) return FQL_ERR_LAUNCH;
-    // 32-row blocks that can hold real rows: every expert's rows rounded up to 32
+    // 8-row workgroups over the padded rows that can hold real rows (every expert's rows rounded up to 32), plus
+    // (MoE entry point) the workgroups that zero the rows of `out` no expert covers
     const int mblocks = (tpe == nullptr) ? (T + FQL_MB - 1) / FQL_MB : (T + FQL_MB * E) / FQL_MB;
-    hipLaunchKernelGGL((act_limbs_kernel<L>), dim3(mblocks, Kp / FQL_KB), dim3(256), 0, st, x, gather, n_src, w.delta,
-                       w.limbs, T, K, Kp / FQL_KB, MBT, tpe, offs, E);
+    const int rblocks = mblocks * (FQL_MB / ACT_ROWS);
+    const int zblocks = (tpe != nullptr && out != nullptr) ? (T + 255) / 256 : 0;
+    const bool vec = (K % 16 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+    auto kern = vec ? act_fused_kernel<L, true> : act_fused_kernel<L, false>;
+    hipLaunchKernelGGL(kern, dim3(rblocks + zblocks), dim3(256), 0, st, x, gather, n_src, w.delta, w.rowsum, w.limbs,
+                       T, K, Kp / FQL_KB, MBT, rblocks, out, N, tpe, offs, E);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
