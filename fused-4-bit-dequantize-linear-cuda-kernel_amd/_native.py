@@ -18,6 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.environ.get("FQL_INT4_LIB") or os.path.join(CSRC, "libfql_int4.so")   # env override: experiments only
 
 PRECISION_DEFAULT = 0
+PRECISION_INT8 = 1
 PRECISION_FAST = 2
 PRECISION_EXACT = 3
 

@@ -6,6 +6,7 @@
 #include "fql_common.h"
 #include "fql_act_quant.h"
 #include "fql_gemm_i8.h"
+#include "fql_gemm_rows32.h"
 #include "fql_gemv.h"
 #include "fql_generic.h"
 #include "fql_quantize.h"
@@ -22,7 +23,8 @@ inline int row_blocks(int T, int E) { return (T + FQL_MB * E + 128 + FQL_MB - 1)
 inline int limbs_of(int precision)
 {
     if (precision == FQL_PRECISION_DEFAULT) return 3;
-    if (precision == FQL_PRECISION_FAST || precision == FQL_PRECISION_EXACT) return precision;
+    if (precision == FQL_PRECISION_INT8 || precision == FQL_PRECISION_FAST || precision == FQL_PRECISION_EXACT)
+        return precision;
     return -1;
 }
 
@@ -62,8 +64,18 @@ struct TileShape { int bm, bn; };
     X(6, 4, 1, 2, 8, 4)        /* 128 x  64, 4 waves: skinny tiles for few rows (HBM-bound: many small */ \
     X(7, 2, 2, 1, 8, 4)        /*  64 x  64, 4 waves   workgroups per CU, 4 weight stages in flight, deep */ \
     X(8, 1, 2, 1, 8, 4)        /*  32 x  64, 2 waves   A ring to cover L2 latency) */ \
-    X(9, 4, 2, 3, 2, 2)        /* 128 x 192, 2 weight stages in flight */
+    X(9, 2, 4, 3, 2, 1)        /*  64 x 384: 64-row groups with the A-fragment reuse of the 128 x 192 tile */
 constexpr int FQL_NUM_CFG = 10;
+// Short row groups (fql_gemm_rows32.h): 32-row tiles, K split KG ways inside the workgroup.  ids 100 + i.
+// R(i, NF, KG, A-ring depth)
+#define FQL_ROWS32_LIST(R)                                                                                         \
+    R(0, 2, 4, 4)              /* 32 x 128 */ \
+    R(1, 2, 8, 4)              /* 32 x  64 */ \
+    R(2, 2, 2, 4)              /* 32 x 256 */ \
+    R(3, 1, 8, 4)              /* 32 x  32 */ \
+    R(4, 1, 4, 4)              /* 32 x  64, one fragment per wave */
+constexpr int FQL_NUM_ROWS32 = 5;
+inline bool valid_cfg(int cfg) { return (cfg >= 0 && cfg < FQL_NUM_CFG) || (cfg >= 100 && cfg < 100 + FQL_NUM_ROWS32); }
 
 // The MFMA path addresses its operands through 32-bit buffer offsets.
 inline bool mfma_addressable(int L, int T, int E, int K, int N)
@@ -134,6 +146,31 @@ int launch_gemm_cfg(const Workspace &w, const uint8_t *packed, const float *scal
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
+template <int L, int NF, int KG, int DEPTH>
+int launch_rows32_cfg(const Workspace &w, const uint8_t *packed, const float *scales, const float *zps, float *out,
+                      const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT, int N,
+                      hipStream_t st)
+{
+    using C = Rows32Cfg<L, NF, KG, DEPTH>;
+    auto kern = gemm_i8_rows32_kernel<L, NF, KG, DEPTH>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                C::LDS_BYTES) != hipSuccess)
+            return FQL_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int n_tiles = (N + C::BN - 1) / C::BN;
+    const int m_slots = (tpe == nullptr) ? (T + C::BM - 1) / C::BM : T / C::BM + E;
+    long long blocks = (long long)n_tiles * m_slots;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return FQL_ERR_BAD_SHAPE;
+    const int cus = compute_units();                         // persistent: one 8-wave workgroup per CU
+    if (blocks > cus) blocks = cus;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, w.limbs, w.delta, w.rowsum,
+                       packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots);
+    return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
+}
+
 template <int L>
 int launch_gemm(int cfg, const Workspace &w, const uint8_t *packed, const float *scales, const float *zps,
                 float *out, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT, int N,
@@ -145,6 +182,11 @@ int launch_gemm(int cfg, const Workspace &w, const uint8_t *packed, const float 
         return launch_gemm_cfg<L, wm, wn, nf, d, bp>(w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, st);
         FQL_CFG_LIST(X)
 #undef X
+#define R(i, nf, kg, d)                                                                                            \
+    case 100 + i:                                                                                                 \
+        return launch_rows32_cfg<L, nf, kg, d>(w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, st);
+        FQL_ROWS32_LIST(R)
+#undef R
     default: return FQL_ERR_BAD_SHAPE;
     }
 }
@@ -167,15 +209,15 @@ inline int choose_cfg(int L, int E, int T, int K, int N, bool grouped)
         if (m <= 64) return 7;                               //  64 x 64, 4 waves
         return 6;                                            // 128 x 64, 4 waves
     }
-    if (m <= 32) return 5;                                   //  32 x 256
-    if (m <= 64) return 4;                                   //  64 x 256
+    if (m <= 32) return 100;                                 //  32 x 128, K split 4 ways inside the workgroup
+    if (m <= 64) return 9;                                   //  64 x 384
     const int mt = groups * ((m + 127) / 128);
     struct Cand { int cfg, bn; };
     // 3 limbs: 128 x 192 with a 2-step A ring (register budget) / 128 x 128; 2 limbs: 4-step ring, + 128 x 256
     const Cand c3[2] = {{0, 192}, {1, 128}};
     const Cand c2[3] = {{3, 192}, {1, 128}, {2, 256}};
-    const Cand *cands = (L == 2) ? c2 : c3;
-    const int nc = (L == 2) ? 3 : 2;
+    const Cand *cands = (L <= 2) ? c2 : c3;
+    const int nc = (L <= 2) ? 3 : 2;
     int best = cands[0].cfg;
     long long best_cost = -1;
     for (int i = 0; i < nc; ++i) {
@@ -199,6 +241,11 @@ int run_mfma(int L, const float *x, const int32_t *gather, int n_src, const uint
     float *zero_out = (tpe != nullptr) ? out : nullptr;
     const int cfg = choose_cfg(L, E, T, K, N, tpe != nullptr);
     int rc;
+    if (L == 1) {
+        rc = launch_act_quant<1>(x, gather, n_src, w, T, K, Kp, MBT, zero_out, N, tpe, offs, E, st);
+        if (rc != FQL_OK) return rc;
+        return launch_gemm<1>(cfg, w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, st);
+    }
     if (L == 2) {
         rc = launch_act_quant<2>(x, gather, n_src, w, T, K, Kp, MBT, zero_out, N, tpe, offs, E, st);
         if (rc != FQL_OK) return rc;
@@ -255,7 +302,7 @@ const char *fql_error_string(int code)
     case FQL_ERR_ODD_K: return "input_dim (K) must be even: two 4-bit weights per packed byte";
     case FQL_ERR_WORKSPACE: return "workspace is NULL, not 16-byte aligned, or smaller than *_workspace_bytes()";
     case FQL_ERR_LAUNCH: return "kernel launch failed (hipGetLastError)";
-    case FQL_ERR_BAD_PRECISION: return "precision must be FQL_PRECISION_DEFAULT, _FAST (2) or _EXACT (3)";
+    case FQL_ERR_BAD_PRECISION: return "precision must be FQL_PRECISION_DEFAULT, _INT8 (1), _FAST (2) or _EXACT (3)";
     case FQL_ERR_ALIGNMENT: return "tensor base pointer not aligned as documented";
     default: return "unknown error code";
     }
@@ -400,6 +447,7 @@ int fql_act_quant_f32(const float *x, int8_t *limbs, float *delta, int32_t *rows
     w.limbs = limbs; w.delta = delta; w.rowsum = rowsum; w.bytes = 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int Kp = padded_k(K), MBT = row_blocks(T, E);
+    if (L == 1) return launch_act_quant<1>(x, nullptr, 0, w, T, K, Kp, MBT, nullptr, 0, tokens_per_expert, input_offsets, E, st);
     if (L == 2) return launch_act_quant<2>(x, nullptr, 0, w, T, K, Kp, MBT, nullptr, 0, tokens_per_expert, input_offsets, E, st);
     return launch_act_quant<3>(x, nullptr, 0, w, T, K, Kp, MBT, nullptr, 0, tokens_per_expert, input_offsets, E, st);
 }
@@ -445,7 +493,7 @@ static int gemm_i8_entry(int cfg, const int8_t *limbs, const float *delta, const
     if ((K % 32) != 0 || !aligned16(packed) || !aligned16(limbs)) return FQL_ERR_ALIGNMENT;
     if (!mfma_addressable(L, T, E, K, N)) return FQL_ERR_BAD_SHAPE;
     if (cfg < 0) cfg = choose_cfg(L, E, T, K, N, tokens_per_expert != nullptr);
-    if (cfg >= FQL_NUM_CFG) return FQL_ERR_BAD_SHAPE;
+    if (!valid_cfg(cfg)) return FQL_ERR_BAD_SHAPE;
     Workspace w;
     w.limbs = const_cast<int8_t *>(limbs);
     w.delta = const_cast<float *>(delta);
@@ -453,6 +501,8 @@ static int gemm_i8_entry(int cfg, const int8_t *limbs, const float *delta, const
     w.bytes = 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int Kp = padded_k(K), MBT = row_blocks(T, E);
+    if (L == 1)
+        return launch_gemm<1>(cfg, w, packed, scales, zps, out, tokens_per_expert, input_offsets, E, T, K, Kp, MBT, N, st);
     if (L == 2)
         return launch_gemm<2>(cfg, w, packed, scales, zps, out, tokens_per_expert, input_offsets, E, T, K, Kp, MBT, N, st);
     return launch_gemm<3>(cfg, w, packed, scales, zps, out, tokens_per_expert, input_offsets, E, T, K, Kp, MBT, N, st);
@@ -473,12 +523,13 @@ FQL_API int fql_tune_gemm_i8_f32(int cfg, const int8_t *limbs, const float *delt
                                  const int32_t *tokens_per_expert, const int32_t *input_offsets, float *out, int E,
                                  int T, int K, int N, int precision, void *stream)
 {
-    if (cfg < 0 || cfg >= FQL_NUM_CFG) return FQL_ERR_BAD_SHAPE;
+    if (!valid_cfg(cfg)) return FQL_ERR_BAD_SHAPE;
     return gemm_i8_entry(cfg, limbs, delta, rowsum, packed, scales, zps, tokens_per_expert, input_offsets, out, E, T,
                          K, N, precision, stream);
 }
 
 FQL_API int fql_tune_num_configs(void) { return FQL_NUM_CFG; }
+FQL_API int fql_tune_num_rows32_configs(void) { return FQL_NUM_ROWS32; }
 
 
 }  // extern "C"

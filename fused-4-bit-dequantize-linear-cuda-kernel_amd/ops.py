@@ -14,14 +14,14 @@ import torch
 from . import _native
 
 _PRECISIONS = {"default": _native.PRECISION_DEFAULT, "exact": _native.PRECISION_EXACT,
-               "fast": _native.PRECISION_FAST, 0: 0, 2: 2, 3: 3}
+               "fast": _native.PRECISION_FAST, "int8": _native.PRECISION_INT8, 0: 0, 1: 1, 2: 2, 3: 3}
 
 
 def _precision(p):
     try:
         return _PRECISIONS[p]
     except KeyError:
-        raise ValueError(f"precision must be 'default', 'exact' or 'fast', got {p!r}") from None
+        raise ValueError(f"precision must be 'default', 'exact', 'fast' or 'int8', got {p!r}") from None
 
 
 def _stream_ptr(device):

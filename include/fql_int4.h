@@ -62,8 +62,13 @@ extern "C" {
  *   FQL_PRECISION_EXACT : 3 limbs, 23-bit fixed point -> float32-class results (default;
  *                         meets the reference's own allclose(atol=1e-3) GPU tests)
  *   FQL_PRECISION_FAST  : 2 limbs, 15-bit fixed point -> ~3e-5 relative (Frobenius) error,
- *                         2/3 of the matrix-core work                                        */
+ *                         2/3 of the matrix-core work
+ *   FQL_PRECISION_INT8  : 1 limb, 8-bit activations (per-row power-of-two scale) -> ~5e-3 relative
+ *                         error, 1/3 of the matrix-core work: the "8-bit activations + INT4 weights"
+ *                         serving mode (outside the 1e-3 parity claim; for weight-streaming-bound
+ *                         shapes such as 64 experts x 7168 -> 18432)                          */
 #define FQL_PRECISION_DEFAULT 0
+#define FQL_PRECISION_INT8 1
 #define FQL_PRECISION_FAST 2
 #define FQL_PRECISION_EXACT 3
 

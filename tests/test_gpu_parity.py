@@ -10,7 +10,8 @@ import pytest
 import torch
 
 from conftest import load_golden
-from helpers import (EXACT_REL_FRO, FAST_REL_FRO, FMA_REL_FRO, rel_fro, act_limbs_reference, decode_limbs)
+from helpers import (EXACT_REL_FRO, FAST_REL_FRO, INT8_REL_FRO, FMA_REL_FRO, rel_fro, act_limbs_reference,
+                     decode_limbs)
 from oracle import oracle as O
 from oracle import c_oracle as C
 
@@ -63,7 +64,7 @@ def test_dequantize_bit_exact(fq):
     assert np.array_equal(got2, got)
 
 
-@pytest.mark.parametrize("L,prec", [(3, "exact"), (2, "fast")])
+@pytest.mark.parametrize("L,prec", [(3, "exact"), (2, "fast"), (1, "int8")])
 def test_activation_limbs_bit_exact(fq, L, prec):
     """The pre-pass (phase 1) against a numpy restatement of the same fixed-point rule."""
     from fused_int4_amd import ops
@@ -191,7 +192,7 @@ def test_gemv_path(fq, B, N, K):
 
 @pytest.mark.parametrize("B,N,K", [(5, 64, 128), (8, 96, 32), (33, 200, 96), (64, 192, 256), (100, 1000, 544),
                                    (128, 256, 1024), (129, 193, 2048), (300, 400, 320), (512, 384, 4096)])
-@pytest.mark.parametrize("prec,tol", [("exact", EXACT_REL_FRO), ("fast", FAST_REL_FRO)])
+@pytest.mark.parametrize("prec,tol", [("exact", EXACT_REL_FRO), ("fast", FAST_REL_FRO), ("int8", INT8_REL_FRO)])
 def test_mfma_path_shapes(fq, B, N, K, prec, tol):
     """B > 4 with K % 32 == 0: activation pre-pass + MFMA GEMM; ragged M, N and K tails."""
     from fused_int4_amd import ops
@@ -319,7 +320,7 @@ def make_moe(E, N, K, counts, seed, gap_rows=0, wscale=0.02):
     (100, 64, 64, [(7 * i) % 5 for i in range(100)], 4),     # > 64 experts: multi-chunk device-side expert table
     (70, 96, 128, [0] * 64 + [33, 0, 1, 40, 0, 2], 0),       # all the work behind the first 64-expert chunk
 ])
-@pytest.mark.parametrize("prec,tol", [("exact", EXACT_REL_FRO), ("fast", FAST_REL_FRO)])
+@pytest.mark.parametrize("prec,tol", [("exact", EXACT_REL_FRO), ("fast", FAST_REL_FRO), ("int8", INT8_REL_FRO)])
 def test_moe_grouped_parity(fq, E, N, K, counts, gap, prec, tol):
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(fq.__file__), "dropin"))
@@ -331,7 +332,7 @@ def test_moe_grouped_parity(fq, E, N, K, counts, gap, prec, tol):
         out = ext.forward(dev(P), dev(S), dev(Z), dev(x), expert_ids, dev(cnt), dev(offs)).cpu().numpy()
     else:
         from fused_int4_amd import ops
-        out = ops.moe_forward(dev(P), dev(S), dev(Z), dev(x), None, dev(cnt), dev(offs), precision="fast").cpu().numpy()
+        out = ops.moe_forward(dev(P), dev(S), dev(Z), dev(x), None, dev(cnt), dev(offs), precision=prec).cpu().numpy()
     ref = C.moe_grouped(P, S, Z, x, cnt, offs)
     assert out.shape == (T, N)
     assert rel_fro(out, ref) < (tol if K % 32 == 0 else FMA_REL_FRO)
@@ -339,6 +340,39 @@ def test_moe_grouped_parity(fq, E, N, K, counts, gap, prec, tol):
     for c, o in zip(cnt, offs):
         covered[o:o + c] = True
     assert (out[~covered] == 0).all()                        # torch::zeros semantics (reference :109)
+
+
+@pytest.mark.parametrize("prec,tol", [("exact", EXACT_REL_FRO), ("fast", FAST_REL_FRO), ("int8", INT8_REL_FRO)])
+def test_every_tile_configuration_is_bit_identical(fq, prec, tol):
+    """The integer dot products are exact, so the tile shape, the K split inside a workgroup and the row
+    grouping must not change a single output bit: sweep every compiled configuration (wide tiles 0..,
+    short-row-group tiles 100..) through the tuning entry point on a ragged grouped problem."""
+    import ctypes
+    from fused_int4_amd import ops, _native
+    lib = _native.lib()
+    tune = lib.fql_tune_gemm_i8_f32
+    tune.restype = ctypes.c_int
+    tune.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+    E, N, K = 5, 200, 768                                    # N % 32 != 0, three 256-k stages
+    counts = [0, 7, 33, 70, 129]
+    P, S, Z, x, cnt, offs = make_moe(E, N, K, counts, 123)
+    T = x.shape[0]
+    dP, dS, dZ, dx, dc, do = dev(P), dev(S), dev(Z), dev(x), dev(cnt), dev(offs)
+    limbs, delta, rowsum = ops.act_quant(dx, precision=prec, tokens_per_expert=dc, input_offsets=do)
+    stream = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    for cfg in list(range(lib.fql_tune_num_configs())) + list(range(100, 100 + lib.fql_tune_num_rows32_configs())):
+        out = torch.full((T, N), float("nan"), dtype=torch.float32, device="cuda")
+        rc = tune(cfg, limbs.data_ptr(), delta.data_ptr(), rowsum.data_ptr(), dP.data_ptr(), dS.data_ptr(),
+                  dZ.data_ptr(), dc.data_ptr(), do.data_ptr(), out.data_ptr(), E, T, K, N,
+                  {"exact": 3, "fast": 2, "int8": 1}[prec], stream)
+        assert rc == 0, (cfg, rc)
+        torch.cuda.synchronize()
+        outs[cfg] = out.cpu().numpy()
+    ref = C.moe_grouped(P, S, Z, x, cnt, offs)
+    assert rel_fro(outs[0], ref) < tol
+    for cfg, o in outs.items():
+        assert np.array_equal(o, outs[0]), f"configuration {cfg} differs from configuration 0"
 
 
 def test_moe_equals_per_expert_linear_bitwise(fq):

@@ -2,7 +2,7 @@
 """A/B the MFMA GEMM tile configurations on the GPU in ONE process (interleaved rounds), checking that
 every configuration returns bit-identical outputs (the integer dot products are exact).
 
-    python tools/tune_gemm.py [--workload moe|linear512] [--precision exact|fast] [--cfgs 0,1,2] [--rounds 5]
+    python tools/tune_gemm.py [--workload moe|linear512|linear (--tokens rows)] [--precision exact|fast] [--cfgs 0,1,2] [--rounds 5]
 """
 import argparse
 import ctypes
@@ -64,7 +64,7 @@ def main():
         for i in range(a.sets):
             w = torch.randn(N, K, device=dev, generator=g) * 0.02
             sets.append(fq.quantize_weights(w))
-        x = torch.randn(512, K, device=dev, generator=g)
+        x = torch.randn(a.tokens if a.workload == "linear" else 512, K, device=dev, generator=g)
         tp, of, En = None, None, 1
     T = x.shape[0]
     limbs, delta, rowsum = ops.act_quant(x, precision=prec, tokens_per_expert=tpe if a.workload == "moe" else None,
