@@ -44,6 +44,15 @@ struct GemmCfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
+// Debug builds (-DFQL_TRACE, tools/trace_kernel.py): wave 0 of the first 8 workgroups stamps the shader clock
+// (s_memtime) at every phase boundary and the constant 100 MHz clock (s_memrealtime) at tile boundaries.
+#if defined(FQL_TRACE)
+__device__ unsigned long long fql_trace_wide[8 * 64];
+#define FQL_WSTAMP(i, real) do { if (blockIdx.x < 8 && threadIdx.x == 0 && (i) < 64) fql_trace_wide[blockIdx.x * 64 + (i)] = (real) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FQL_WSTAMP(i, real) do { } while (0)
+#endif
+
 __device__ __forceinline__ void wait_lgkmcnt0() { __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14)); }
 
 
@@ -77,7 +86,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     }
 
     n_real = __builtin_amdgcn_readfirstlane(n_real);
+  int ev = 0;
   for (int vb = blockIdx.x; vb < n_real; vb += gridDim.x) {
+    FQL_WSTAMP(ev++, 1);                                     // tile start, constant 100 MHz clock
+    FQL_WSTAMP(ev++, 0);                                     // tile start, shader clock
     int e = 0, row0 = 0, rows_valid = 0, prow0 = 0;
     const int tile = xcd_remap(vb, n_real);
     const int ms = tile / n_tiles;
@@ -212,6 +224,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
                 const int v = ks >> 1, b = ks & 1;
                 const int pc = v & 1, pn = (v + 1) & 1;          // raw-register set of this pair / the next pair
                 if (ks == 0) {
+                    FQL_WSTAMP(ev++, 0);                     // stage start
                     // the other LDS stage was released by the barrier of stage kt-1: park stage kt+1 there now,
                     // then refill that ring slot with stage kt+1+BD (BD stages of HBM lead).
                 #pragma unroll
@@ -259,10 +272,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
                 }
                 // refill the ring slot just consumed with the A fragments D steps ahead
                 const int nks = ks + D;
+#if !(defined(FQL_ABLATE) && FQL_ABLATE == 2)      // ablation 2: no A refills (timing experiment only, wrong results)
 #pragma unroll
                 for (int l = 0; l < L; ++l)
                     afr[ks % D][l] = __builtin_amdgcn_raw_buffer_load_b128(
                         rsA, aoff[l], (kt + nks / KS) * a_stage + (nks % KS) * 1024, 0);
+#else
+                (void)nks;
+#endif
                 // pin the software pipeline: without this the machine scheduler sinks the prefetch loads
                 // down to their use D steps later (load; s_waitcnt vmcnt(0); mfma) to save registers.
                 __builtin_amdgcn_sched_barrier(0);
@@ -293,6 +310,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
         continue;
     }
 
+    FQL_WSTAMP(ev++, 0);                                     // K loop done
     // ---- epilogue: fold zero-point, combine limbs, scale.  The weights are the MFMA's A operand (rows = n)
     //      and the activations its B operand (cols = t), so in the 32x32 C/D layout
     //      (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) every lane owns ONE output
@@ -310,26 +328,46 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     float *orow = out + (size_t)t * N;
     const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(sce) & 15) == 0) && ((reinterpret_cast<uintptr_t>(zpe) & 15) == 0);
+    if (vec) {
+        // scale / zero-point vectors through bounds-checked buffer loads (columns past N read as zero), issued one
+        // fragment AHEAD of the arithmetic that uses them: unconditional, so they batch instead of paying one
+        // memory round trip per 4 columns
+        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void *)sce, 0, N * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void *)zpe, 0, N * 4, 0x00020000);
+        v4f s4[2][4], z4[2][4];
+        auto fetch = [&](int j, int slot) {
 #pragma unroll
-    for (int j = 0; j < NF; ++j)
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + (wn * NF + j) * 32 + 8 * q + 4 * g;
+                s4[slot][q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsS, n * 4, 0, 0));
+                z4[slot][q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsZ, n * 4, 0, 0));
+            }
+        };
+        fetch(0, 0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int n = n0 + (wn * NF + j) * 32 + 8 * q + 4 * g;
-            if (n >= N) continue;
-            float o[4];
-            if (vec) {                                       // n % 4 == 0 and N % 4 == 0: all four columns exist
-                const v4f s4 = *reinterpret_cast<const v4f *>(sce + n);
-                const v4f z4 = *reinterpret_cast<const v4f *>(zpe + n);
+        for (int j = 0; j < NF; ++j) {
+            if (j + 1 < NF) fetch(j + 1, (j + 1) & 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + (wn * NF + j) * 32 + 8 * q + 4 * g;
+                float o[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float tot = 0.0f;
 #pragma unroll
                     for (int l = L - 1; l >= 0; --l)
-                        tot = fmaf(tot, 256.0f, fmaf(-z4[c], rs[l], (float)acc[l][j][4 * q + c]));
-                    o[c] = (tot * d) * s4[c];
+                        tot = fmaf(tot, 256.0f, fmaf(-z4[j & 1][q][c], rs[l], (float)acc[l][j][4 * q + c]));
+                    o[c] = (tot * d) * s4[j & 1][q][c];
                 }
-                *reinterpret_cast<v4f *>(orow + n) = v4f{o[0], o[1], o[2], o[3]};
-            } else {
+                if (n < N) *reinterpret_cast<v4f *>(orow + n) = v4f{o[0], o[1], o[2], o[3]};   // N % 4 == 0
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + (wn * NF + j) * 32 + 8 * q + 4 * g;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     if (n + c >= N) continue;
@@ -340,7 +378,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
                     orow[n + c] = (tot * d) * sce[n + c];
                 }
             }
-        }
+    }
+    FQL_WSTAMP(ev++, 0);                                     // epilogue issued
+    FQL_WSTAMP(ev++, 1);
   }   // persistent tile loop
 #endif  // __HIP_DEVICE_COMPILE__
 }

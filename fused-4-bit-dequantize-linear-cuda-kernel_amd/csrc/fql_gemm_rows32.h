@@ -15,7 +15,7 @@
 #include "fql_common.h"
 #include "fql_gemm_i8.h"
 
-template <int L, int NF, int KG, int DEPTH>
+template <int L, int NF, int KG, int DEPTH, int BDEPTH, int OCC = 2>
 struct Rows32Cfg {
     static constexpr int NW = 8;
     static constexpr int NG = NW / KG;                        // column groups of the workgroup
@@ -23,7 +23,9 @@ struct Rows32Cfg {
     static constexpr int BM = FQL_MB;
     static constexpr int BN = 32 * NF * NG;
     static constexpr int KS = FQL_KB / 32;
-    static constexpr int D = DEPTH;
+    static constexpr int D = DEPTH;                           // A prefetch depth in k-steps
+    static constexpr int BD = BDEPTH;                         // weight stages in flight per wave (register ring)
+    static constexpr int WG_PER_CU = OCC / 2;                 // OCC waves per SIMD = OCC / 2 workgroups of 8 waves per CU
     static constexpr int PIECES = NF * 4;                     // 1 KiB weight pieces per wave per 256-k stage
     static constexpr int SLAB = NF * 32 * (FQL_KB / 2);       // wave-private LDS bytes (one stage of packed weights)
     static constexpr int ACC_BYTES = L * NF * 16 * 64 * 4;    // one wave's accumulators
@@ -31,11 +33,22 @@ struct Rows32Cfg {
     static constexpr int LDS_BYTES = (NW * SLAB > RED_BYTES) ? NW * SLAB : RED_BYTES;
     static_assert(KG == 1 || KG == 2 || KG == 4 || KG == 8, "K split");
     static_assert(KS % D == 0, "ring depth must divide the steps per stage");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(LDS_BYTES * WG_PER_CU <= 160 * 1024, "LDS budget");
 };
 
-template <int L, int NF, int KG, int DEPTH>
-__global__ __launch_bounds__(512, 2) void gemm_i8_rows32_kernel(
+#if defined(FQL_TRACE)
+__device__ unsigned long long fql_trace_buf[8 * 64];         // [block < 8][event]: s_memtime stamps of wave 0
+#define FQL_STAMP(i) do { if (blockIdx.x < 8 && threadIdx.x == 0 && (i) < 64) fql_trace_buf[blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FQL_STAMP(i) do { } while (0)
+#endif
+
+struct Rows32Tile {            // wave-uniform description of one 32-row x BN tile
+    int e, row0, prow0, rows_valid, nt, ok;
+};
+
+template <int L, int NF, int KG, int DEPTH, int BDEPTH, int OCC>
+__global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
     const int8_t *__restrict__ limbs, const float *__restrict__ delta,
     const int32_t *__restrict__ rowsum, const uint8_t *__restrict__ packed,
     const float *__restrict__ scales, const float *__restrict__ zps, float *__restrict__ out,
@@ -43,8 +56,9 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_rows32_kernel(
     int E, int T, int K, int Kp, int MBT, int N, int n_tiles, int m_slots)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using C = Rows32Cfg<L, NF, KG, DEPTH>;
-    constexpr int KS = C::KS, D = C::D, NG = C::NG;
+    using C = Rows32Cfg<L, NF, KG, DEPTH, BDEPTH, OCC>;
+    constexpr int KS = C::KS, D = C::D, NG = C::NG, BD = C::BD;
+    constexpr int OOB = 0x7fff0000;                           // a buffer offset past every descriptor: reads zero
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x;
@@ -62,62 +76,62 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_rows32_kernel(
     }
     n_real = __builtin_amdgcn_readfirstlane(n_real);
 
-  for (int vb = blockIdx.x; vb < n_real; vb += gridDim.x) {
-    // ---- tile -> (expert, 32-row block, column block); m-tile major so neighbours share activations in L2
-    int e = 0, row0 = 0, rows_valid = 0, prow0 = 0;
-    const int tile = xcd_remap(vb, n_real);
-    const int ms = tile / n_tiles;
-    const int nt = tile - ms * n_tiles;
-    if (tpe == nullptr) {
-        row0 = prow0 = ms * C::BM;
-        rows_valid = T - row0;
-    } else {
-        int cp = 0, ct = 0;
-        bool found = false;
-        for (int base = 0; base < E && !found; base += 64) {
-            const ExpertLane x = expert_chunk(tpe, offs, E, T, C::BM, base, lane, cp, ct);
-            const unsigned long long hit = __ballot(ms >= x.tile_excl && ms < x.tile_excl + x.tiles);
-            if (hit) {
-                const int src = __ffsll((long long)hit) - 1;
-                const int lo = __shfl(x.lo, src, 64), cnt = __shfl(x.cnt, src, 64);
-                const int te = __shfl(x.tile_excl, src, 64), pe = __shfl(x.pad_excl, src, 64);
-                e = base + src;
-                row0 = lo + (ms - te) * C::BM;
-                prow0 = pe + (ms - te) * C::BM;
-                rows_valid = cnt - (ms - te) * C::BM;
-                found = true;
+    // ---- tile id -> (expert, 32-row block, column block); m-tile major so neighbours share activations in L2
+    auto tile_params = [&](int vb) -> Rows32Tile {
+        Rows32Tile tp = {0, 0, 0, 0, 0, 0};
+        if (vb >= n_real) return tp;
+        const int tile = xcd_remap(vb, n_real);
+        const int ms = tile / n_tiles;
+        tp.nt = tile - ms * n_tiles;
+        if (tpe == nullptr) {
+            tp.row0 = tp.prow0 = ms * C::BM;
+            tp.rows_valid = T - tp.row0;
+            tp.ok = 1;
+        } else {
+            int cp = 0, ct = 0;
+            for (int base = 0; base < E && !tp.ok; base += 64) {
+                const ExpertLane x = expert_chunk(tpe, offs, E, T, C::BM, base, lane, cp, ct);
+                const unsigned long long hit = __ballot(ms >= x.tile_excl && ms < x.tile_excl + x.tiles);
+                if (hit) {
+                    const int src = __ffsll((long long)hit) - 1;
+                    const int lo = __shfl(x.lo, src, 64), cnt = __shfl(x.cnt, src, 64);
+                    const int te = __shfl(x.tile_excl, src, 64), pe = __shfl(x.pad_excl, src, 64);
+                    tp.e = base + src;
+                    tp.row0 = lo + (ms - te) * C::BM;
+                    tp.prow0 = pe + (ms - te) * C::BM;
+                    tp.rows_valid = cnt - (ms - te) * C::BM;
+                    tp.ok = 1;
+                }
             }
         }
-        if (!found) continue;                                 // uniform over the workgroup
-    }
-    if (rows_valid <= 0) continue;
-    if (rows_valid > C::BM) rows_valid = C::BM;
-    const int n0 = nt * C::BN + ng * NF * 32;                 // first column of this wave
-    e = __builtin_amdgcn_readfirstlane(e);
-    row0 = __builtin_amdgcn_readfirstlane(row0);
-    prow0 = __builtin_amdgcn_readfirstlane(prow0);
-    rows_valid = __builtin_amdgcn_readfirstlane(rows_valid);
+        if (tp.rows_valid <= 0) tp.ok = 0;
+        if (tp.rows_valid > C::BM) tp.rows_valid = C::BM;
+        tp.e = __builtin_amdgcn_readfirstlane(tp.e);
+        tp.row0 = __builtin_amdgcn_readfirstlane(tp.row0);
+        tp.prow0 = __builtin_amdgcn_readfirstlane(tp.prow0);
+        tp.rows_valid = __builtin_amdgcn_readfirstlane(tp.rows_valid);
+        tp.nt = __builtin_amdgcn_readfirstlane(tp.nt);
+        tp.ok = __builtin_amdgcn_readfirstlane(tp.ok);
+        return tp;
+    };
 
-    const int KB = Kp / FQL_KB;
+    const int KB = Kp / FQL_KB, KT = KB;
+    const int SP = ((KT + KG - 1) / KG + BD - 1) / BD * BD;   // stages per wave per tile, padded to the ring depth
     const size_t wbytes = (size_t)N * (size_t)(K >> 1);
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
         (void *)limbs, 0, (int)((size_t)L * KB * MBT * 8192), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(packed + (size_t)e * wbytes), 0, (int)wbytes, 0x00020000);
-
-    const int mb = prow0 >> 5;
-    int aoff[L];
-#pragma unroll
-    for (int l = 0; l < L; ++l) aoff[l] = ((l * KB) * MBT + mb) * 8192 + lane * 16;
     const int a_stage = MBT * 8192;
 
-    // ---- wave-private weight slab: piece i = rows 8i..8i+7 of this wave's NF*32 rows, 128 B each
+    // ---- per-lane offsets that do not depend on the tile: everything tile-specific goes into the scalar offset
+    int aoffl[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) aoffl[l] = (l * KB) * MBT * 8192 + lane * 16;
     char *slab = lds + wave * C::SLAB;
-    int voffB[C::PIECES], wB[C::PIECES];
+    int vrel[C::PIECES], wB[C::PIECES];                       // piece i = rows 8i..8i+7 of this wave's NF*32 rows
 #pragma unroll
     for (int i = 0; i < C::PIECES; ++i) {
         const int row = i * 8 + (lane >> 3), ch = lane & 7;
-        voffB[i] = (n0 + row) * (K >> 1) + ch * 16;          // rows past N fall outside the descriptor: zeros
+        vrel[i] = row * (K >> 1) + ch * 16;
         wB[i] = row * 128 + 16 * (ch ^ ((row >> 1) & 7));
     }
     int rB[NF], swB[NF];
@@ -127,6 +141,49 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_rows32_kernel(
         rB[j] = n * 128;
         swB[j] = (n >> 1) & 7;
     }
+    // scalar offsets of (tile, stage index s of this K group [, k-step]); past the tile's K range or for a
+    // missing tile the weights read as zero (the activations may then be anything)
+    auto w_soff = [&](const Rows32Tile &tp, int s) -> int {
+        const int kt = kg + s * KG;
+        return (tp.ok && kt < KT) ? (tp.nt * C::BN + ng * NF * 32) * (K >> 1) + kt * (FQL_KB / 2) : OOB;
+    };
+    auto a_soff = [&](const Rows32Tile &tp, int s, int ks) -> int {
+        const int kt = kg + s * KG;
+        return (tp.ok && kt < KT) ? (tp.prow0 >> 5) * 8192 + kt * a_stage + ks * 1024 : 0;
+    };
+    auto w_rsrc = [&](const Rows32Tile &tp) {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(packed + (size_t)tp.e * wbytes), 0, (int)wbytes, 0x00020000);
+    };
+
+    // ---- rings: BD weight stages and D activation k-steps in flight, running ACROSS tile boundaries so that a
+    //      tile's reduction and epilogue hide the next tile's first HBM round trip
+    v4i bst[BD][C::PIECES];
+    v4i afr[D][L];
+    int ev = 0;
+    FQL_STAMP(ev++);                                          // 0: kernel entry (after n_real)
+    Rows32Tile cur = tile_params(blockIdx.x);
+    FQL_STAMP(ev++);                                          // 1: first tile params
+    {
+        const __amdgpu_buffer_rsrc_t rs = w_rsrc(cur);
+#pragma unroll
+        for (int u = 0; u < BD; ++u) {
+            const int so = w_soff(cur, u);
+#pragma unroll
+            for (int i = 0; i < C::PIECES; ++i) bst[u][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vrel[i], so, 0);
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int so = a_soff(cur, 0, d);
+#pragma unroll
+            for (int l = 0; l < L; ++l) afr[d][l] = __builtin_amdgcn_raw_buffer_load_b128(rsA, aoffl[l], so, 0);
+        }
+    }
+
+  for (int vb = blockIdx.x; vb < n_real; vb += gridDim.x) {
+    FQL_STAMP(ev++);                                          // tile: start
+    const Rows32Tile nxt = tile_params(vb + gridDim.x);
+    FQL_STAMP(ev++);                                          // tile: next params known
+    const __amdgpu_buffer_rsrc_t rs_cur = w_rsrc(cur), rs_nxt = w_rsrc(nxt);
 
     v16i acc[L][NF];
 #pragma unroll
@@ -137,66 +194,77 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_rows32_kernel(
             for (int r = 0; r < 16; ++r) acc[l][j][r] = 0;
 
     // ---- K loop over this K group's stages kg, kg+KG, ...: no barriers, wave-local ordering only
-    const int KT = KB;
-    if (kg < KT) {
-        v4i bst[C::PIECES];
-        v4i afr[D][L];
+    for (int s0 = 0; s0 < SP; s0 += BD) {
 #pragma unroll
-        for (int i = 0; i < C::PIECES; ++i) bst[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], kg * (FQL_KB / 2), 0);
+      for (int u = 0; u < BD; ++u) {                          // unrolled: the ring slot is static
+        const int s = s0 + u;
+        FQL_STAMP(ev++);                                      // tile: stage start
+        // LDS operations of one wave execute in order: these writes cannot overtake the previous stage's
+        // fragment reads
 #pragma unroll
-        for (int s = 0; s < D; ++s)
+        for (int i = 0; i < C::PIECES; ++i) *reinterpret_cast<v4i *>(slab + wB[i]) = bst[u][i];
+        {   // refill the slot with the stage BD ahead (the next tile's first stages near the end of this one)
+            const bool here = s + BD < SP;
+            const int so = here ? w_soff(cur, s + BD) : w_soff(nxt, s + BD - SP);
+            if (here) {
 #pragma unroll
-            for (int l = 0; l < L; ++l)
-                afr[s][l] = __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff[l], kg * a_stage + s * 1024, 0);
-        for (int kt = kg; kt < KT; kt += KG) {
-            // LDS operations of one wave execute in order: these writes cannot overtake the previous stage's
-            // fragment reads (all consumed by its MFMAs already)
+                for (int i = 0; i < C::PIECES; ++i) bst[u][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, vrel[i], so, 0);
+            } else {
 #pragma unroll
-            for (int i = 0; i < C::PIECES; ++i) *reinterpret_cast<v4i *>(slab + wB[i]) = bst[i];
-            // next stage of this K group (past the end: wrong rows or zeros, never used)
-#pragma unroll
-            for (int i = 0; i < C::PIECES; ++i)
-                bst[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], (kt + KG) * (FQL_KB / 2), 0);
-            v4i braw[NF];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int v = ks >> 1, b = ks & 1;
-                if (b == 0) {
-#pragma unroll
-                    for (int j = 0; j < NF; ++j)
-                        braw[j] = *reinterpret_cast<const v4i *>(slab + rB[j] + 16 * ((2 * v + g) ^ swB[j]));
-                }
-                v4i bfr[NF];
-#pragma unroll
-                for (int j = 0; j < NF; ++j) {
-                    uint32_t lo0, hi0, lo1, hi1;
-                    unpack8((uint32_t)braw[j][2 * b], lo0, hi0);
-                    unpack8((uint32_t)braw[j][2 * b + 1], lo1, hi1);
-                    bfr[j] = v4i{(int)lo0, (int)hi0, (int)lo1, (int)hi1};
-                }
-#pragma unroll
-                for (int l = 0; l < L; ++l)
-#pragma unroll
-                    for (int j = 0; j < NF; ++j)
-                        acc[l][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bfr[j], afr[ks % D][l], acc[l][j], 0, 0, 0);
-                const int nks = ks + D;                      // refill the ring slot D steps ahead
-#pragma unroll
-                for (int l = 0; l < L; ++l)
-                    afr[ks % D][l] = __builtin_amdgcn_raw_buffer_load_b128(
-                        rsA, aoff[l], (kt + (nks / KS) * KG) * a_stage + (nks % KS) * 1024, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < C::PIECES; ++i) bst[u][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_nxt, vrel[i], so, 0);
             }
         }
+        v4i braw[NF];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int v = ks >> 1, b = ks & 1;
+            if (b == 0) {
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    braw[j] = *reinterpret_cast<const v4i *>(slab + rB[j] + 16 * ((2 * v + g) ^ swB[j]));
+            }
+            v4i bfr[NF];
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                uint32_t lo0, hi0, lo1, hi1;
+                unpack8((uint32_t)braw[j][2 * b], lo0, hi0);
+                unpack8((uint32_t)braw[j][2 * b + 1], lo1, hi1);
+                bfr[j] = v4i{(int)lo0, (int)hi0, (int)lo1, (int)hi1};
+            }
+#if defined(FQL_ABLATE) && FQL_ABLATE == 1          // timing experiments only (wrong results)
+#pragma unroll
+            for (int l = 0; l < L; ++l) asm volatile("" ::"v"(afr[ks % D][l]));
+#pragma unroll
+            for (int j = 0; j < NF; ++j) asm volatile("" ::"v"(bfr[j]));
+#else
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    acc[l][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bfr[j], afr[ks % D][l], acc[l][j], 0, 0, 0);
+#endif
+            {   // refill the A ring slot D steps ahead (next stage / next tile near the end)
+                const int nks = ks + D;
+                int so;
+                if (nks < KS) so = a_soff(cur, s, nks);
+                else so = (s + 1 < SP) ? a_soff(cur, s + 1, nks - KS) : a_soff(nxt, 0, nks - KS);
+#pragma unroll
+                for (int l = 0; l < L; ++l) afr[ks % D][l] = __builtin_amdgcn_raw_buffer_load_b128(rsA, aoffl[l], so, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
 
+    FQL_STAMP(ev++);                                          // tile: K loop done
     // ---- add the KG partial accumulators through LDS, pairwise (int32: exact, order-free).  The weight slabs
-    //      are dead by the first barrier.
+    //      are dead by the first barrier; the next tile's first loads are already in flight.
     if (KG > 1) {
 #pragma unroll
-        for (int s = 1; s < KG; s <<= 1) {
-            char *red = lds + ((kg / (2 * s)) * NG + ng) * C::ACC_BYTES;
+        for (int sft = 1; sft < KG; sft <<= 1) {
+            char *red = lds + ((kg / (2 * sft)) * NG + ng) * C::ACC_BYTES;
             __syncthreads();                                  // slabs / previous round's partials consumed
-            if ((kg & (2 * s - 1)) == s) {
+            if ((kg & (2 * sft - 1)) == sft) {
 #pragma unroll
                 for (int l = 0; l < L; ++l)
 #pragma unroll
@@ -207,7 +275,7 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_rows32_kernel(
                                 v4i{acc[l][j][4 * q], acc[l][j][4 * q + 1], acc[l][j][4 * q + 2], acc[l][j][4 * q + 3]};
             }
             __syncthreads();
-            if ((kg & (2 * s - 1)) == 0) {
+            if ((kg & (2 * sft - 1)) == 0) {
 #pragma unroll
                 for (int l = 0; l < L; ++l)
 #pragma unroll
@@ -222,17 +290,20 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_rows32_kernel(
         }
         __syncthreads();                                      // the next tile's slabs overwrite the partials
     }
-    if (kg != 0) continue;
 
+    FQL_STAMP(ev++);                                          // tile: reduction done
     // ---- epilogue (as the wide kernel): lane owns output row t, registers 4q..4q+3 are 4 consecutive columns
-    if (l31 >= rows_valid) continue;
-    const int t = row0 + l31;
+    const Rows32Tile done = cur;
+    cur = nxt;
+    if (kg != 0 || !done.ok || l31 >= done.rows_valid) continue;
+    const int n0 = done.nt * C::BN + ng * NF * 32;
+    const int t = done.row0 + l31;
     const float d = delta[t];
-    float rs[L];
+    float rsum[L];
 #pragma unroll
-    for (int l = 0; l < L; ++l) rs[l] = (float)rowsum[(size_t)l * T + t];
-    const float *sce = scales + (size_t)e * N;
-    const float *zpe = zps + (size_t)e * N;
+    for (int l = 0; l < L; ++l) rsum[l] = (float)rowsum[(size_t)l * T + t];
+    const float *sce = scales + (size_t)done.e * N;
+    const float *zpe = zps + (size_t)done.e * N;
     float *orow = out + (size_t)t * N;
     const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(sce) & 15) == 0) && ((reinterpret_cast<uintptr_t>(zpe) & 15) == 0);
@@ -251,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_rows32_kernel(
                     float tot = 0.0f;
 #pragma unroll
                     for (int l = L - 1; l >= 0; --l)
-                        tot = fmaf(tot, 256.0f, fmaf(-z4[c], rs[l], (float)acc[l][j][4 * q + c]));
+                        tot = fmaf(tot, 256.0f, fmaf(-z4[c], rsum[l], (float)acc[l][j][4 * q + c]));
                     o[c] = (tot * d) * s4[c];
                 }
                 *reinterpret_cast<v4f *>(orow + n) = v4f{o[0], o[1], o[2], o[3]};
@@ -262,7 +333,7 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_rows32_kernel(
                     float tot = 0.0f;
 #pragma unroll
                     for (int l = L - 1; l >= 0; --l)
-                        tot = fmaf(tot, 256.0f, fmaf(-zpe[n + c], rs[l], (float)acc[l][j][4 * q + c]));
+                        tot = fmaf(tot, 256.0f, fmaf(-zpe[n + c], rsum[l], (float)acc[l][j][4 * q + c]));
                     orow[n + c] = (tot * d) * sce[n + c];
                 }
             }

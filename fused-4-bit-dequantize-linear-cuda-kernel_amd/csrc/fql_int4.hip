@@ -54,7 +54,7 @@ inline Workspace carve(void *base, int L, int T, int E, int Kp)
 // ---- MFMA tile configurations (see fql_gemm_i8.h): 8 waves as WM x WN, NF 32-column fragments per wave.
 struct TileShape { int bm, bn; };
 // X(id, WM, WN, NF, A-ring depth in k-steps, weight stages in flight)
-#define FQL_CFG_LIST(X)        \
+#define FQL_CFG_LIST(X)                                                                                            \
     X(0, 4, 2, 3, 2, 1)        /* 128 x 192 (3 limbs: 2-step A ring is what the register budget allows) */ \
     X(1, 4, 2, 2, 4, 1)        /* 128 x 128 */ \
     X(2, 4, 2, 4, 2, 1)        /* 128 x 256 (2-limb register budget) */ \
@@ -64,17 +64,21 @@ struct TileShape { int bm, bn; };
     X(6, 4, 1, 2, 8, 4)        /* 128 x  64, 4 waves: skinny tiles for few rows (HBM-bound: many small */ \
     X(7, 2, 2, 1, 8, 4)        /*  64 x  64, 4 waves   workgroups per CU, 4 weight stages in flight, deep */ \
     X(8, 1, 2, 1, 8, 4)        /*  32 x  64, 2 waves   A ring to cover L2 latency) */ \
-    X(9, 2, 4, 3, 2, 1)        /*  64 x 384: 64-row groups with the A-fragment reuse of the 128 x 192 tile */
-constexpr int FQL_NUM_CFG = 10;
+    X(9, 2, 4, 3, 2, 1)        /*  64 x 384: 64-row groups with the A-fragment reuse of the 128 x 192 tile */ \
+    X(10, 2, 4, 3, 4, 2)       /*  64 x 384, 2 weight stages in flight (1- and 2-limb register budgets) */
+constexpr int FQL_NUM_CFG = 11;
 // Short row groups (fql_gemm_rows32.h): 32-row tiles, K split KG ways inside the workgroup.  ids 100 + i.
-// R(i, NF, KG, A-ring depth)
+// R(i, NF, KG, A-ring depth in k-steps, weight stages in flight per wave, waves per SIMD)
 #define FQL_ROWS32_LIST(R)                                                                                         \
-    R(0, 2, 4, 4)              /* 32 x 128 */ \
-    R(1, 2, 8, 4)              /* 32 x  64 */ \
-    R(2, 2, 2, 4)              /* 32 x 256 */ \
-    R(3, 1, 8, 4)              /* 32 x  32 */ \
-    R(4, 1, 4, 4)              /* 32 x  64, one fragment per wave */
-constexpr int FQL_NUM_ROWS32 = 5;
+    R(0, 2, 4, 2, 2, 2)        /* 32 x 128 */ \
+    R(1, 2, 8, 2, 1, 2)        /* 32 x  64 */ \
+    R(2, 2, 2, 2, 2, 2)        /* 32 x 256 */ \
+    R(3, 2, 4, 2, 1, 2)        /* 32 x 128, one weight stage in flight */ \
+    R(4, 1, 4, 4, 2, 2)        /* 32 x  64, one fragment per wave */ \
+    R(5, 1, 4, 2, 1, 4)        /* 32 x  64, <= 128 registers: two workgroups per CU hide each other's HBM waits */ \
+    R(6, 1, 8, 2, 1, 4)        /* 32 x  32, two workgroups per CU */ \
+    R(7, 1, 2, 2, 1, 4)        /* 32 x 128, two workgroups per CU */
+constexpr int FQL_NUM_ROWS32 = 8;
 inline bool valid_cfg(int cfg) { return (cfg >= 0 && cfg < FQL_NUM_CFG) || (cfg >= 100 && cfg < 100 + FQL_NUM_ROWS32); }
 
 // The MFMA path addresses its operands through 32-bit buffer offsets.
@@ -146,13 +150,13 @@ int launch_gemm_cfg(const Workspace &w, const uint8_t *packed, const float *scal
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
-template <int L, int NF, int KG, int DEPTH>
+template <int L, int NF, int KG, int DEPTH, int BDEPTH, int OCC>
 int launch_rows32_cfg(const Workspace &w, const uint8_t *packed, const float *scales, const float *zps, float *out,
                       const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT, int N,
                       hipStream_t st)
 {
-    using C = Rows32Cfg<L, NF, KG, DEPTH>;
-    auto kern = gemm_i8_rows32_kernel<L, NF, KG, DEPTH>;
+    using C = Rows32Cfg<L, NF, KG, DEPTH, BDEPTH, OCC>;
+    auto kern = gemm_i8_rows32_kernel<L, NF, KG, DEPTH, BDEPTH, OCC>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -164,7 +168,7 @@ int launch_rows32_cfg(const Workspace &w, const uint8_t *packed, const float *sc
     const int m_slots = (tpe == nullptr) ? (T + C::BM - 1) / C::BM : T / C::BM + E;
     long long blocks = (long long)n_tiles * m_slots;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return FQL_ERR_BAD_SHAPE;
-    const int cus = compute_units();                         // persistent: one 8-wave workgroup per CU
+    const int cus = compute_units() * C::WG_PER_CU;          // persistent: WG_PER_CU 8-wave workgroups per CU
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, w.limbs, w.delta, w.rowsum,
                        packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots);
@@ -182,9 +186,10 @@ int launch_gemm(int cfg, const Workspace &w, const uint8_t *packed, const float 
         return launch_gemm_cfg<L, wm, wn, nf, d, bp>(w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, st);
         FQL_CFG_LIST(X)
 #undef X
-#define R(i, nf, kg, d)                                                                                            \
+#define R(i, nf, kg, d, bd, occ)                                                                                   \
     case 100 + i:                                                                                                 \
-        return launch_rows32_cfg<L, nf, kg, d>(w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, st);
+        return launch_rows32_cfg<L, nf, kg, d, bd, occ>(w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, \
+                                                        st);
         FQL_ROWS32_LIST(R)
 #undef R
     default: return FQL_ERR_BAD_SHAPE;
@@ -528,6 +533,16 @@ FQL_API int fql_tune_gemm_i8_f32(int cfg, const int8_t *limbs, const float *delt
                          K, N, precision, stream);
 }
 
+#if defined(FQL_TRACE)
+FQL_API int fql_debug_trace_wide(unsigned long long *dst)
+{
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(fql_trace_wide), sizeof(unsigned long long) * 8 * 64) == hipSuccess ? 0 : -1;
+}
+FQL_API int fql_debug_trace(unsigned long long *dst)
+{
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(fql_trace_buf), sizeof(unsigned long long) * 8 * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 FQL_API int fql_tune_num_configs(void) { return FQL_NUM_CFG; }
 FQL_API int fql_tune_num_rows32_configs(void) { return FQL_NUM_ROWS32; }
 
