@@ -36,12 +36,13 @@ struct GemmCfg {
     static constexpr int KS = FQL_KB / 32;                   // MFMA k-steps per weight stage (8)
     static constexpr int D = DEPTH;                          // A prefetch depth in k-steps (register ring)
     static constexpr int B_STAGE = BN * (FQL_KB / 2);        // bytes of packed weights per stage
-    static constexpr int LDS_BYTES = 2 * B_STAGE;
+    static constexpr int LDS_BYTES = 2 * B_STAGE + 2 * 2 * BN * 4;   // two weight stages + two scale / zero-point slices
     static constexpr int CPWB = BN / 8 / NW;                 // 1 KiB weight pieces per wave per stage
     static_assert(NW == 8 || NW == 4 || NW == 2, "8 waves (two per SIMD), or small 4 / 2-wave workgroups for skinny tiles");
     static_assert(KS % D == 0, "ring depth must divide the steps per stage");
     static_assert((BN / 8) % NW == 0, "weight pieces must divide evenly over the waves");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static constexpr int SZN = (2 * BN + THREADS - 1) / THREADS;      // scale / zero-point floats staged per thread
 };
 
 // Debug builds (-DFQL_TRACE, tools/trace_kernel.py): wave 0 of the first 8 workgroups stamps the shader clock
@@ -52,6 +53,10 @@ __device__ unsigned long long fql_trace_wide[8 * 64];
 #else
 #define FQL_WSTAMP(i, real) do { } while (0)
 #endif
+
+struct GemmTile {              // wave-uniform description of one BM x BN tile
+    int e, row0, prow0, rows_valid, nt, ok;
+};
 
 __device__ __forceinline__ void wait_lgkmcnt0() { __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14)); }
 
@@ -70,97 +75,138 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     // ---- tiles.  Real m-tiles are counted on the device (expert counts live there).  The launch is
-    //      PERSISTENT: one workgroup per CU walks virtual block ids vb = blockIdx.x, +gridDim.x, ...; the
-    //      16-byte stores of one tile's epilogue drain while the next tile's loads and MFMAs start.
+    //      PERSISTENT: one workgroup per CU walks virtual block ids vb = blockIdx.x, +gridDim.x, ...
     //      Logical tile ids are m-tile major and dealt to XCDs in contiguous ranges (vb % 8 = the XCD
     //      group of the workgroup, for every vb it visits), so the workgroups of one XCD share an
     //      expert's activation panel in that XCD's L2 while each weight byte streams once.
-    const int lane0 = threadIdx.x & 63;
-    int n_real = m_slots * n_tiles;
-    if (tpe != nullptr) {
-        // One vector load per 64 experts (every wave does it redundantly; nothing is shared).
-        int cp = 0, ct = 0;
-        for (int base = 0; base < E; base += 64) (void)expert_chunk(tpe, offs, E, T, C::BM, base, lane0, cp, ct);
-        const int m_tiles = ct < m_slots ? ct : m_slots;     // overlapping ranges: stay inside the plan
-        n_real = m_tiles * n_tiles;
-    }
-
-    n_real = __builtin_amdgcn_readfirstlane(n_real);
-  int ev = 0;
-  for (int vb = blockIdx.x; vb < n_real; vb += gridDim.x) {
-    FQL_WSTAMP(ev++, 1);                                     // tile start, constant 100 MHz clock
-    FQL_WSTAMP(ev++, 0);                                     // tile start, shader clock
-    int e = 0, row0 = 0, rows_valid = 0, prow0 = 0;
-    const int tile = xcd_remap(vb, n_real);
-    const int ms = tile / n_tiles;
-    const int nt = tile - ms * n_tiles;
-    if (tpe == nullptr) {                                   // linear: one group covering all T rows
-        row0 = prow0 = ms * C::BM;
-        rows_valid = T - row0;
-    } else {                                                // MoE: the expert that owns this m-tile
-        int cp = 0, ct = 0;
-        bool found = false;
-        for (int base = 0; base < E && !found; base += 64) {
-            const ExpertLane x = expert_chunk(tpe, offs, E, T, C::BM, base, lane0, cp, ct);   // re-read per tile: keeps no table live in registers
-            const unsigned long long hit = __ballot(ms >= x.tile_excl && ms < x.tile_excl + x.tiles);
-            if (hit) {
-                const int src = __ffsll((long long)hit) - 1;
-                const int lo = __shfl(x.lo, src, 64), cnt = __shfl(x.cnt, src, 64);
-                const int te = __shfl(x.tile_excl, src, 64), pe = __shfl(x.pad_excl, src, 64);
-                e = base + src;
-                row0 = lo + (ms - te) * C::BM;
-                prow0 = pe + (ms - te) * C::BM;
-                rows_valid = cnt - (ms - te) * C::BM;
-                found = true;
-            }
-        }
-        if (!found) continue;
-    }
-    if (rows_valid <= 0) continue;
-    if (rows_valid > C::BM) rows_valid = C::BM;
-    const int n0 = nt * C::BN;
-    e = __builtin_amdgcn_readfirstlane(e);
-    row0 = __builtin_amdgcn_readfirstlane(row0);
-    prow0 = __builtin_amdgcn_readfirstlane(prow0);
-    rows_valid = __builtin_amdgcn_readfirstlane(rows_valid);
-
+    //      The NEXT tile's first loads (its stage-0 weights, its scale / zero-point slice, its first
+    //      activation fragments) are issued BEFORE the current tile's epilogue arithmetic and stores, so the
+    //      HBM round trip of one tile's prologue hides under the other's VALU-bound epilogue.
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave - wm * WN;
     const int l31 = lane & 31, g = lane >> 5;
-    const bool active = wm * FQL_MB < rows_valid;           // waves past the expert's last row only help stage weights
+    int n_real = m_slots * n_tiles;
+    if (tpe != nullptr) {
+        // One vector load per 64 experts (every wave does it redundantly; nothing is shared).
+        int cp = 0, ct = 0;
+        for (int base = 0; base < E; base += 64) (void)expert_chunk(tpe, offs, E, T, C::BM, base, lane, cp, ct);
+        const int m_tiles = ct < m_slots ? ct : m_slots;     // overlapping ranges: stay inside the plan
+        n_real = m_tiles * n_tiles;
+    }
+    n_real = __builtin_amdgcn_readfirstlane(n_real);
 
-    // ---- buffer descriptors (bounds-checked: weight rows past N and the K tail read as zero)
-    const int KB = Kp / FQL_KB;
+    auto tile_params = [&](int vb) -> GemmTile {             // wave-uniform
+        GemmTile tp = {0, 0, 0, 0, 0, 0};
+        if (vb >= n_real) return tp;
+        const int tile = xcd_remap(vb, n_real);
+        const int ms = tile / n_tiles;
+        tp.nt = tile - ms * n_tiles;
+        if (tpe == nullptr) {                                // linear: one group covering all T rows
+            tp.row0 = tp.prow0 = ms * C::BM;
+            tp.rows_valid = T - tp.row0;
+            tp.ok = 1;
+        } else {                                             // MoE: the expert that owns this m-tile
+            int cp = 0, ct = 0;
+            for (int base = 0; base < E && !tp.ok; base += 64) {
+                const ExpertLane x = expert_chunk(tpe, offs, E, T, C::BM, base, lane, cp, ct);
+                const unsigned long long hit = __ballot(ms >= x.tile_excl && ms < x.tile_excl + x.tiles);
+                if (hit) {
+                    const int src = __ffsll((long long)hit) - 1;
+                    const int lo = __shfl(x.lo, src, 64), cnt = __shfl(x.cnt, src, 64);
+                    const int te = __shfl(x.tile_excl, src, 64), pe = __shfl(x.pad_excl, src, 64);
+                    tp.e = base + src;
+                    tp.row0 = lo + (ms - te) * C::BM;
+                    tp.prow0 = pe + (ms - te) * C::BM;
+                    tp.rows_valid = cnt - (ms - te) * C::BM;
+                    tp.ok = 1;
+                }
+            }
+        }
+        if (tp.rows_valid <= 0) tp.ok = 0;
+        if (tp.rows_valid > C::BM) tp.rows_valid = C::BM;
+        tp.e = __builtin_amdgcn_readfirstlane(tp.e);
+        tp.row0 = __builtin_amdgcn_readfirstlane(tp.row0);
+        tp.prow0 = __builtin_amdgcn_readfirstlane(tp.prow0);
+        tp.rows_valid = __builtin_amdgcn_readfirstlane(tp.rows_valid);
+        tp.nt = __builtin_amdgcn_readfirstlane(tp.nt);
+        tp.ok = __builtin_amdgcn_readfirstlane(tp.ok);
+        return tp;
+    };
+
+    // ---- everything per-lane is tile independent; the tile enters through scalar offsets and descriptors
+    constexpr int OOB = 0x7fff0000;                          // a buffer offset past every descriptor: reads zero
+    constexpr int BD = C::BD;
+    const int KB = Kp / FQL_KB, KT = KB;                     // weight stages (K padded to 256 by the pre-pass)
     const size_t wbytes = (size_t)N * (size_t)(K >> 1);
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
         (void *)limbs, 0, (int)((size_t)L * KB * MBT * 8192), 0x00020000);
+    const int a_stage = MBT * 8192;                          // bytes between consecutive kb of one limb
+    // A operand: limbs[l][kb][mb][ks][lane][16 B]
+    // (one base register per address family; the fragment / piece / limb index goes into the scalar offset or the
+    //  instruction's immediate, which keeps ~10 VGPRs out of a 256-register kernel)
+    const int aoff0 = lane * 16;
+    const int a_limb = KB * MBT * 8192;                      // bytes between the limbs of one (kb, mb) block
+    // weight staging: piece p = i*8 + wave covers rows 8p..8p+7 of the tile, 128 B each (8 full lines)
+    //  piece i: rows + i * 8 * NW -> + i * 8 * NW * (K/2) bytes in memory, + i * NW KiB in the LDS image (the
+    //  XOR swizzle repeats every 16 rows); fragment j: rows + 32 j -> + 4 KiB j in LDS, same swizzle
+    const int row0B = wave * 8 + (lane >> 3), chB = lane & 7;
+    const int voffB0 = row0B * (K >> 1) + chB * 16;
+    const int pieceB = 8 * C::NW * (K >> 1);
+    const int wB0 = row0B * 128 + 16 * (chB ^ ((row0B >> 1) & 7));      // swizzled LDS image
+    const int nB0 = wn * NF * 32 + l31;
+    const int rB0 = nB0 * 128;
+    const int swB0 = (nB0 >> 1) & 7;
+    // scale / zero-point slice of a tile: 2 * BN floats through LDS (thread i < BN: scale of column i, thread
+    // BN + i: zero point), double buffered by tile parity so the epilogue needs no global loads for them
+    float *szbuf = reinterpret_cast<float *>(lds + 2 * C::B_STAGE);
+
+    v4i bst[BD][C::CPWB];                                    // weight stages in flight (global -> VGPR -> LDS)
+    v4i afr[D][L];                                           // A ring: D k-steps ahead
+    float szr[C::SZN];
+
+    // first loads of a tile.  Every load is UNCONDITIONAL (a missing tile, rows past N and columns past N read
+    // zero through the descriptors): a load under an `if` makes hipcc's counted vmcnt collapse to "wait for
+    // almost everything", which throws the prefetch lead away.
+    auto issue_prologue = [&](const GemmTile &tp) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(packed + (size_t)tp.e * wbytes), 0, (int)wbytes, 0x00020000);
+        const int sB = tp.ok ? tp.nt * C::BN * (K >> 1) : OOB;
+#pragma unroll
+        for (int i = 0; i < C::CPWB; ++i) bst[0][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voffB0, sB + i * pieceB, 0);
+        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(scales + (size_t)tp.e * N), 0, N * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(zps + (size_t)tp.e * N), 0, N * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < C::SZN; ++i) {
+            const int idx = tid + i * C::THREADS;            // < BN: scale of column idx; then zero points
+            const bool is_s = idx < C::BN;
+            const int col = is_s ? idx : idx - C::BN;
+            const int so = (tp.ok && idx < 2 * C::BN) ? 0 : OOB;
+            const int vo = (tp.nt * C::BN + col) * 4;
+            const int vs = __builtin_amdgcn_raw_buffer_load_b32(rsS, is_s ? vo : OOB, so, 0);
+            const int vz = __builtin_amdgcn_raw_buffer_load_b32(rsZ, is_s ? OOB : vo, so, 0);
+            szr[i] = __builtin_bit_cast(float, vs | vz);     // the other one read zero
+        }
+    };
+
+  int ev = 0;
+  GemmTile cur = tile_params(blockIdx.x);
+  issue_prologue(cur);
+  int parity = 0;
+  for (int vb = blockIdx.x; vb < n_real; vb += gridDim.x, parity ^= 1) {
+    FQL_WSTAMP(ev++, 1);                                     // tile start, constant 100 MHz clock
+    FQL_WSTAMP(ev++, 0);                                     // tile start, shader clock
+    const int e = cur.e, row0 = cur.row0, rows_valid = cur.rows_valid;
+    const int n0 = cur.nt * C::BN;
+    const bool active = cur.ok && wm * FQL_MB < rows_valid; // waves past the expert's last row only help stage weights
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(packed + (size_t)e * wbytes), 0, (int)wbytes, 0x00020000);
-
-    // ---- A operand: limbs[l][kb][mb][ks][lane][16 B]; this wave's row block is mb
-    const int mb = (prow0 >> 5) + wm;
-    int aoff[L];
-#pragma unroll
-    for (int l = 0; l < L; ++l) aoff[l] = ((l * KB) * MBT + mb) * 8192 + lane * 16;
-    const int a_stage = MBT * 8192;                         // bytes between consecutive kb of one limb
-
-    // ---- weight staging: piece p = i*8 + wave covers rows 8p..8p+7, 128 B each (8 full lines)
-    int voffB[C::CPWB], wB[C::CPWB];
-#pragma unroll
-    for (int i = 0; i < C::CPWB; ++i) {
-        const int row = (i * C::NW + wave) * 8 + (lane >> 3), ch = lane & 7;
-        voffB[i] = (n0 + row) * (K >> 1) + ch * 16;
-        wB[i] = row * 128 + 16 * (ch ^ ((row >> 1) & 7));   // swizzled LDS image
-    }
-    int rB[NF], swB[NF];
-#pragma unroll
-    for (int j = 0; j < NF; ++j) {
-        const int n = (wn * NF + j) * 32 + l31;
-        rB[j] = n * 128;
-        swB[j] = (n >> 1) & 7;
-    }
+    const int sB = n0 * (K >> 1);                            // scalar part of this tile's weight offsets
+    const int sA = ((cur.prow0 >> 5) + wm) * 8192;           // ... and of its activation offsets
+    float *sz = szbuf + parity * 2 * C::BN;
 
     v16i acc[L][NF];
 #pragma unroll
@@ -170,35 +216,31 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[l][j][r] = 0;
 
-    const int KT = KB;                                       // weight stages (K padded to 256 by the pre-pass)
-    v4i afr[D][L];                                           // A ring: D k-steps ahead
-
-    // ---- prologue: stage 0 of the weights into LDS, stages 1..BD into the staging-register ring (slot of
-    //      stage s = s % BD), A for steps 0..D-1.  Every prefetch below is UNCONDITIONAL: past the last stage
-    //      the buffer offsets fall outside the descriptors and the loads return zero.  (A load under an `if`
-    //      makes hipcc's counted vmcnt collapse to "wait for almost everything", which throws the prefetch
-    //      lead away.)
-    constexpr int BD = C::BD;
-    v4i bst[BD][C::CPWB];                                    // weight stages in flight (global -> VGPR -> LDS)
+   if (cur.ok) {
+    // ---- stage 0 of the weights (in flight since the previous tile's epilogue) into LDS, stages 1..BD into
+    //      the staging-register ring (slot of stage s = s % BD)
 #pragma unroll
-    for (int i = 0; i < C::CPWB; ++i) bst[0][i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], 0, 0);
+    for (int i = 0; i < C::CPWB; ++i) *reinterpret_cast<v4i *>(lds + wB0 + i * C::NW * 1024) = bst[0][i];
 #pragma unroll
-    for (int i = 0; i < C::CPWB; ++i) *reinterpret_cast<v4i *>(lds + wB[i]) = bst[0][i];
+    for (int i = 0; i < C::SZN; ++i)
+        if (tid + i * C::THREADS < 2 * C::BN) sz[tid + i * C::THREADS] = szr[i];
 #pragma unroll
     for (int s = 1; s <= BD; ++s)
 #pragma unroll
         for (int i = 0; i < C::CPWB; ++i)
-            bst[s % BD][i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], s * (FQL_KB / 2), 0);
+            bst[s % BD][i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB0, (s < KT ? sB + s * (FQL_KB / 2) : OOB) + i * pieceB, 0);
 
     if (active) {
         // ---- the weight fragments are software-pipelined one k-step ahead: the ds_reads of the next 64-k
         //      pair and the nibble unpack of the next step are issued under the current step's MFMAs.  One
         //      barrier per stage, placed at step 5: by then every wave has parked stage kt+1 (its step 0) and
         //      has finished reading stage kt (the last read of it is issued at step 4).
+        //      (The activation ring starts here, not with the early prologue: its 8 * L * D registers would be
+        //      live across the previous tile's epilogue, and these are L2 hits.)
 #pragma unroll
         for (int s = 0; s < D; ++s)
 #pragma unroll
-            for (int l = 0; l < L; ++l) afr[s][l] = __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff[l], s * 1024, 0);
+            for (int l = 0; l < L; ++l) afr[s][l] = __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff0, sA + l * a_limb + s * 1024, 0);
         wait_lgkmcnt0();
         __builtin_amdgcn_s_barrier();
         // ping-pong register sets indexed by compile-time parity (the k-step loop is fully unrolled), so the
@@ -206,7 +248,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
         v4i bfr2[2][NF], braw2[2][NF];
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
-            braw2[0][j] = *reinterpret_cast<const v4i *>(lds + rB[j] + 16 * ((0 + g) ^ swB[j]));
+            braw2[0][j] = *reinterpret_cast<const v4i *>(lds + rB0 + j * 4096 + 16 * ((0 + g) ^ swB0));
             uint32_t lo0, hi0, lo1, hi1;
             unpack8((uint32_t)braw2[0][j][0], lo0, hi0);
             unpack8((uint32_t)braw2[0][j][1], lo1, hi1);
@@ -226,13 +268,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
                 if (ks == 0) {
                     FQL_WSTAMP(ev++, 0);                     // stage start
                     // the other LDS stage was released by the barrier of stage kt-1: park stage kt+1 there now,
-                    // then refill that ring slot with stage kt+1+BD (BD stages of HBM lead).
+                    // then refill that ring slot with stage kt+1+BD (BD stages of HBM lead; past the last stage
+                    // the offset is out of bounds: zeros, no memory traffic).
+                    const int sNext = (kt + 1 + BD < KT) ? sB + (kt + 1 + BD) * (FQL_KB / 2) : OOB;
                 #pragma unroll
-                    for (int i = 0; i < C::CPWB; ++i) *reinterpret_cast<v4i *>(nb + wB[i]) = bst[(kk + 1) % BD][i];
+                    for (int i = 0; i < C::CPWB; ++i) *reinterpret_cast<v4i *>(nb + wB0 + i * C::NW * 1024) = bst[(kk + 1) % BD][i];
 #pragma unroll
                     for (int i = 0; i < C::CPWB; ++i)
                         bst[(kk + 1) % BD][i] =
-                            __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], (kt + 1 + BD) * (FQL_KB / 2), 0);
+                            __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB0, sNext + i * pieceB, 0);
                 }
                 if (ks == 5) {
                     wait_lgkmcnt0();
@@ -243,7 +287,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
                     const int nv = (v + 1) & 3;
 #pragma unroll
                     for (int j = 0; j < NF; ++j)
-                        braw2[pn][j] = *reinterpret_cast<const v4i *>(src + rB[j] + 16 * ((2 * nv + g) ^ swB[j]));
+                        braw2[pn][j] = *reinterpret_cast<const v4i *>(src + rB0 + j * 4096 + 16 * ((2 * nv + g) ^ swB0));
                 }
 #if defined(FQL_ABLATE) && FQL_ABLATE == 1
 #pragma unroll
@@ -276,7 +320,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
 #pragma unroll
                 for (int l = 0; l < L; ++l)
                     afr[ks % D][l] = __builtin_amdgcn_raw_buffer_load_b128(
-                        rsA, aoff[l], (kt + nks / KS) * a_stage + (nks % KS) * 1024, 0);
+                        rsA, aoff0, sA + l * a_limb + (kt + nks / KS) * a_stage + (nks % KS) * 1024, 0);
 #else
                 (void)nks;
 #endif
@@ -297,88 +341,75 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
             const int kt = kt0 + kk;
             if (kt >= KT) break;
             char *nb = lds + ((kt + 1) & 1) * C::B_STAGE;
+            const int sNext = (kt + 1 + BD < KT) ? sB + (kt + 1 + BD) * (FQL_KB / 2) : OOB;
 #pragma unroll
-            for (int i = 0; i < C::CPWB; ++i) *reinterpret_cast<v4i *>(nb + wB[i]) = bst[(kk + 1) % BD][i];
+            for (int i = 0; i < C::CPWB; ++i) *reinterpret_cast<v4i *>(nb + wB0 + i * C::NW * 1024) = bst[(kk + 1) % BD][i];
 #pragma unroll
             for (int i = 0; i < C::CPWB; ++i)
                 bst[(kk + 1) % BD][i] =
-                    __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], (kt + 1 + BD) * (FQL_KB / 2), 0);
+                    __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB0, sNext + i * pieceB, 0);
             wait_lgkmcnt0();
             __builtin_amdgcn_s_barrier();
           }
         }
-        continue;
     }
+   }   // cur.ok
 
     FQL_WSTAMP(ev++, 0);                                     // K loop done
+    // the next tile (its expert-table loads are short and nothing slow is ahead of them in the load queue)
+    const GemmTile nxt = tile_params(vb + gridDim.x);
     // ---- epilogue: fold zero-point, combine limbs, scale.  The weights are the MFMA's A operand (rows = n)
     //      and the activations its B operand (cols = t), so in the 32x32 C/D layout
     //      (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) every lane owns ONE output
-    //      row t and registers 4q..4q+3 are 4 consecutive output columns: 4 per-row loads per lane and
-    //      16-byte stores.
+    //      row t and registers 4q..4q+3 are 4 consecutive output columns: 4 per-row loads per lane, the
+    //      scale / zero-point vectors from LDS, 16-byte stores.
+    //      Order of issue matters (vector-memory loads complete in order): the four short per-row loads first,
+    //      then the next tile's long HBM loads, then the arithmetic and the stores.
     const int rl = wm * FQL_MB + l31;
-    if (rl >= rows_valid) continue;
-    const int t = row0 + rl;
-    const float d = delta[t];
-    float rs[L];
+    const bool row_ok = active && rl < rows_valid;
+    const int t = row_ok ? row0 + rl : 0;
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)delta, 0, T * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)rowsum, 0, L * T * 4, 0x00020000);
+    const float d = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, t * 4, 0, 0));
+    int rsi[L];
 #pragma unroll
-    for (int l = 0; l < L; ++l) rs[l] = (float)rowsum[(size_t)l * T + t];
-    const float *sce = scales + (size_t)e * N;
-    const float *zpe = zps + (size_t)e * N;
-    float *orow = out + (size_t)t * N;
-    const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
-                     ((reinterpret_cast<uintptr_t>(sce) & 15) == 0) && ((reinterpret_cast<uintptr_t>(zpe) & 15) == 0);
-    if (vec) {
-        // scale / zero-point vectors through bounds-checked buffer loads (columns past N read as zero), issued one
-        // fragment AHEAD of the arithmetic that uses them: unconditional, so they batch instead of paying one
-        // memory round trip per 4 columns
-        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void *)sce, 0, N * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void *)zpe, 0, N * 4, 0x00020000);
-        v4f s4[2][4], z4[2][4];
-        auto fetch = [&](int j, int slot) {
+    for (int l = 0; l < L; ++l) rsi[l] = __builtin_amdgcn_raw_buffer_load_b32(rsR, (l * T + t) * 4, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_prologue(nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    if (row_ok) {
+        float rs[L];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + (wn * NF + j) * 32 + 8 * q + 4 * g;
-                s4[slot][q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsS, n * 4, 0, 0));
-                z4[slot][q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsZ, n * 4, 0, 0));
-            }
-        };
-        fetch(0, 0);
+        for (int l = 0; l < L; ++l) rs[l] = (float)rsi[l];
+        float *orow = out + (size_t)t * N;
+        const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
 #pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            if (j + 1 < NF) fetch(j + 1, (j + 1) & 1);
+        for (int j = 0; j < NF; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int n = n0 + (wn * NF + j) * 32 + 8 * q + 4 * g;
+                const int c0 = (wn * NF + j) * 32 + 8 * q + 4 * g;          // column inside the tile
+                const int n = n0 + c0;
+                const v4f s4 = *reinterpret_cast<const v4f *>(sz + c0);
+                const v4f z4 = *reinterpret_cast<const v4f *>(sz + C::BN + c0);
                 float o[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float tot = 0.0f;
 #pragma unroll
                     for (int l = L - 1; l >= 0; --l)
-                        tot = fmaf(tot, 256.0f, fmaf(-z4[j & 1][q][c], rs[l], (float)acc[l][j][4 * q + c]));
-                    o[c] = (tot * d) * s4[j & 1][q][c];
+                        tot = fmaf(tot, 256.0f, fmaf(-z4[c], rs[l], (float)acc[l][j][4 * q + c]));
+                    o[c] = (tot * d) * s4[c];
                 }
-                if (n < N) *reinterpret_cast<v4f *>(orow + n) = v4f{o[0], o[1], o[2], o[3]};   // N % 4 == 0
-            }
-        }
-    } else {
+                if (vec) {
+                    if (n < N) *reinterpret_cast<v4f *>(orow + n) = v4f{o[0], o[1], o[2], o[3]};   // N % 4 == 0
+                } else {
 #pragma unroll
-        for (int j = 0; j < NF; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + (wn * NF + j) * 32 + 8 * q + 4 * g;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (n + c >= N) continue;
-                    float tot = 0.0f;
-#pragma unroll
-                    for (int l = L - 1; l >= 0; --l)
-                        tot = fmaf(tot, 256.0f, fmaf(-zpe[n + c], rs[l], (float)acc[l][j][4 * q + c]));
-                    orow[n + c] = (tot * d) * sce[n + c];
+                    for (int c = 0; c < 4; ++c)
+                        if (n + c < N) orow[n + c] = o[c];
                 }
             }
     }
+    cur = nxt;
     FQL_WSTAMP(ev++, 0);                                     // epilogue issued
     FQL_WSTAMP(ev++, 1);
   }   // persistent tile loop
