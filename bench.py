@@ -266,7 +266,11 @@ def main():
         tfile = os.path.join(ROOT, "profiles", f"pmc_traffic_{a.workload}.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tfile))
+                shape = tj.get("shape", {})
+                same = (shape.get("experts") == a.experts and shape.get("hidden") == K and shape.get("ffn") == N
+                        and shape.get("rows") == rows and prec in ("default", "exact") and a.routing == "balanced")
+                traffic = tj.get("hbm_bytes_per_launch") if same else None     # PMC figure of THIS shape only
             except Exception:
                 traffic = None
         if mfma_floor_ms >= hbm_floor_ms:
