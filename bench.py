@@ -330,6 +330,26 @@ def main():
         ms_fast = time_mode("fast")
         extra["fast_mode_2_limbs"] = {"ms_per_step": ms_fast, "value": flops / (ms_fast * 1e-3) / 1e12, "unit": "TFLOP/s",
                                       "note": "FQL_PRECISION_FAST: ~3e-5 relative error (north-star bound 1e-3); not the headline"}
+        x16 = x.half()
+
+        def time_f16():
+            def step16():
+                P, S, Z = sets[step_i[0] % len(sets)]
+                step_i[0] += 1
+                return ops.moe_forward_any(P, S, Z, x16, None, tpe, offs, precision=prec)
+            for _ in range(5):
+                step16()
+            torch.cuda.synchronize()
+            tf0 = time.perf_counter()
+            nf = max(10, a.steps // 4)
+            for _ in range(nf):
+                step16()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - tf0) / nf * 1e3
+        ms_16 = time_f16()
+        extra["float16_io"] = {"ms_per_step": ms_16, "value": flops / (ms_16 * 1e-3) / 1e12, "unit": "TFLOP/s",
+                               "note": "float16 rows in, float16 out through fql_moe_fwd (widening / rounding fused into the "
+                                       "kernels; same limbs and accumulation as the headline); not the headline"}
         ms_i8 = time_mode("int8")
         extra["int8_mode_1_limb"] = {"ms_per_step": ms_i8, "value": flops / (ms_i8 * 1e-3) / 1e12, "unit": "TFLOP/s",
                                      "hbm_GBps_packed_weights_e2e": weight_bytes / (ms_i8 * 1e-3) / 1e9,

@@ -18,6 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.environ.get("FQL_INT4_LIB") or os.path.join(CSRC, "libfql_int4.so")   # env override: experiments only
 
 PRECISION_DEFAULT = 0
+DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
 PRECISION_INT8 = 1
 PRECISION_FAST = 2
 PRECISION_EXACT = 3
@@ -42,6 +43,11 @@ _SYMBOLS = {
     "fql_act_limb_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
     "fql_act_quant_f32": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fql_gemm_i8_f32": (ctypes.c_int, [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    "fql_native_dtype_supported": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_int]),
+    "fql_linear_fwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5
+                       + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "fql_moe_fwd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 6
+                    + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
 }
 
 _lib = None

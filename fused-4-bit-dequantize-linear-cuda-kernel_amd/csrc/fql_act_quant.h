@@ -65,12 +65,23 @@ __device__ __forceinline__ int act_exponent(float m)
 #define ACT_ROWS 8
 #define ACT_CH 8              // chunks per thread per slab: 32 chunk columns x 8 = 256 chunks = 4096 k
 
-template <int L, bool VEC>
-__global__ __launch_bounds__(256) void act_fused_kernel(
-    const float *__restrict__ x, const int32_t *__restrict__ gather, int n_src, float *__restrict__ delta,
-    int32_t *__restrict__ rowsum, int8_t *__restrict__ limbs, int T, int K, int KB, int MBT, int rblocks,
-    float *__restrict__ out, int N, const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs, int E)
+// IN: element type of x (FQL_DTYPE_F32 / _F16 / _BF16); 16-bit inputs are widened in registers (exact), so the
+// limbs are the ones the float32 copy of x would give.  out_es: bytes per element of `out` (zero fill only).
+template <int IN>
+__device__ __forceinline__ float act_widen(unsigned short h)
 {
+    if (IN == 1) { _Float16 f; __builtin_memcpy(&f, &h, 2); return (float)f; }
+    return __uint_as_float((uint32_t)h << 16);
+}
+
+template <int L, bool VEC, int IN>
+__global__ __launch_bounds__(256) void act_fused_kernel(
+    const void *__restrict__ xin, const int32_t *__restrict__ gather, int n_src, float *__restrict__ delta,
+    int32_t *__restrict__ rowsum, int8_t *__restrict__ limbs, int T, int K, int KB, int MBT, int rblocks,
+    void *__restrict__ out, int out_es, int N, const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
+    int E)
+{
+    constexpr int ES = (IN == 0) ? 4 : 2;         // bytes per element of x
     __shared__ int s_tok[ACT_ROWS];
     __shared__ uint32_t s_max[4][ACT_ROWS];
     __shared__ int s_sum[4][ACT_ROWS][L];
@@ -89,9 +100,14 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
                 covered |= (t >= lo && t < lo + cnt);
             }
         }
-        if (t < T && !covered) {
-            float *orow = out + (size_t)t * N;
-            for (int i = 0; i < N; ++i) orow[i] = 0.0f;      // rare path: rows no expert owns
+        if (t < T && !covered) {                             // rare path: rows no expert owns
+            if (out_es == 4) {
+                float *orow = reinterpret_cast<float *>(out) + (size_t)t * N;
+                for (int i = 0; i < N; ++i) orow[i] = 0.0f;
+            } else {
+                unsigned short *orow = reinterpret_cast<unsigned short *>(out) + (size_t)t * N;
+                for (int i = 0; i < N; ++i) orow[i] = 0;
+            }
         }
         return;
     }
@@ -131,7 +147,8 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
     const int r = tid & 7, col = tid >> 3;        // row of the workgroup, chunk column 0..31
     const int tok = s_tok[r];
     const int p = p0 + r, mb = p >> 5, r32 = p & 31;
-    const float *xr = x + (size_t)(tok >= 0 ? source_row(gather, n_src, tok) : 0) * K;
+    const char *xr = reinterpret_cast<const char *>(xin) +
+                     (size_t)(tok >= 0 ? source_row(gather, n_src, tok) : 0) * K * ES;
     const int nch = KB * 16;                      // 16-float chunks per padded row
     const int slabs = (nch + 32 * ACT_CH - 1) / (32 * ACT_CH);
 
@@ -145,15 +162,34 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
         for (int j = 0; j < ACT_CH; ++j) {
             const int k0 = (slab * 32 * ACT_CH + col + 32 * j) * 16;
             if (VEC) {
-                const float *src = xr + (k0 < K ? k0 : 0);
+                const char *src = xr + (size_t)(k0 < K ? k0 : 0) * ES;
+                if (IN == 0) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) xv[j][q] = *reinterpret_cast<const v4f *>(src + 4 * q);
+                    for (int q = 0; q < 4; ++q) xv[j][q] = *reinterpret_cast<const v4f *>(src + 16 * q);
+                } else {                          // 16 halves = two 16-byte loads
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const v4i raw = *reinterpret_cast<const v4i *>(src + 16 * h);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            xv[j][2 * h + (i >> 1)][2 * (i & 1)] = act_widen<IN>((unsigned short)((uint32_t)raw[i] & 0xFFFFu));
+                            xv[j][2 * h + (i >> 1)][2 * (i & 1) + 1] = act_widen<IN>((unsigned short)((uint32_t)raw[i] >> 16));
+                        }
+                    }
+                }
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        xv[j][q][i] = (k0 + 4 * q + i < K) ? xr[k0 + 4 * q + i] : 0.0f;
+                    for (int i = 0; i < 4; ++i) {
+                        const int k = k0 + 4 * q + i;
+                        float v = 0.0f;
+                        if (k < K) {
+                            if (IN == 0) v = reinterpret_cast<const float *>(xr)[k];
+                            else v = act_widen<IN>(reinterpret_cast<const unsigned short *>(xr)[k]);
+                        }
+                        xv[j][q][i] = v;
+                    }
             }
         }
     };

@@ -45,6 +45,47 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+// ---- output element types (FQL_DTYPE_* of include/fql_int4.h): 0 float32, 1 float16, 2 bfloat16, both rounded
+//      to nearest even exactly as torch's .to(dtype) does
+__device__ __forceinline__ unsigned short f32_to_f16_bits(float f)
+{
+    const _Float16 h = (_Float16)f;
+    unsigned short u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
+}
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((u >> 16) | 0x40u);     // quiet NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+// Four consecutive outputs of row `row_elems` (= t * N) starting at column n.  `vec`: N % 4 == 0 and a suitably
+// aligned base, so the four columns exist and one wide store is legal.
+__device__ __forceinline__ void store_out4(void *out, int kind, size_t row_elems, int n, int N, bool vec, const float (&o)[4])
+{
+    if (kind == 0) {
+        float *p = reinterpret_cast<float *>(out) + row_elems + n;
+        if (vec) { if (n < N) *reinterpret_cast<v4f *>(p) = v4f{o[0], o[1], o[2], o[3]}; }
+        else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (n + c < N) p[c] = o[c];
+        }
+    } else {
+        unsigned short h[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) h[c] = (kind == 1) ? f32_to_f16_bits(o[c]) : f32_to_bf16_bits(o[c]);
+        unsigned short *p = reinterpret_cast<unsigned short *>(out) + row_elems + n;
+        if (vec) {
+            if (n < N) *reinterpret_cast<uint2 *>(p) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (n + c < N) p[c] = h[c];
+        }
+    }
+}
+
 // Bijective XCD-aware remap of a 1-D grid: blocks b and b+8 share an XCD (round-robin dispatch),
 // so give each XCD a contiguous range of logical tile ids.  Speed only, never correctness.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk)

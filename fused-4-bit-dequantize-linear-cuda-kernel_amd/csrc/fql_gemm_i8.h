@@ -65,7 +65,7 @@ template <int L, int WM, int WN, int NF, int DEPTH, int BDEPTH>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     const int8_t *__restrict__ limbs, const float *__restrict__ delta,
     const int32_t *__restrict__ rowsum, const uint8_t *__restrict__ packed,
-    const float *__restrict__ scales, const float *__restrict__ zps, float *__restrict__ out,
+    const float *__restrict__ scales, const float *__restrict__ zps, void *__restrict__ out, int out_kind,
     const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
     int E, int T, int K, int Kp, int MBT, int N, int n_tiles, int m_slots)
 {
@@ -381,14 +381,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
         float rs[L];
 #pragma unroll
         for (int l = 0; l < L; ++l) rs[l] = (float)rsi[l];
-        float *orow = out + (size_t)t * N;
-        const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+        const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & (out_kind == 0 ? 15 : 7)) == 0);
 #pragma unroll
         for (int j = 0; j < NF; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c0 = (wn * NF + j) * 32 + 8 * q + 4 * g;          // column inside the tile
-                const int n = n0 + c0;
                 const v4f s4 = *reinterpret_cast<const v4f *>(sz + c0);
                 const v4f z4 = *reinterpret_cast<const v4f *>(sz + C::BN + c0);
                 float o[4];
@@ -400,13 +398,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
                         tot = fmaf(tot, 256.0f, fmaf(-z4[c], rs[l], (float)acc[l][j][4 * q + c]));
                     o[c] = (tot * d) * s4[c];
                 }
-                if (vec) {
-                    if (n < N) *reinterpret_cast<v4f *>(orow + n) = v4f{o[0], o[1], o[2], o[3]};   // N % 4 == 0
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (n + c < N) orow[n + c] = o[c];
-                }
+                store_out4(out, out_kind, (size_t)t * N, n0 + c0, N, vec, o);
             }
     }
     cur = nxt;

@@ -51,7 +51,7 @@ template <int L, int NF, int KG, int DEPTH, int BDEPTH, int OCC>
 __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
     const int8_t *__restrict__ limbs, const float *__restrict__ delta,
     const int32_t *__restrict__ rowsum, const uint8_t *__restrict__ packed,
-    const float *__restrict__ scales, const float *__restrict__ zps, float *__restrict__ out,
+    const float *__restrict__ scales, const float *__restrict__ zps, void *__restrict__ out, int out_kind,
     const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
     int E, int T, int K, int Kp, int MBT, int N, int n_tiles, int m_slots)
 {
@@ -304,39 +304,38 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
     for (int l = 0; l < L; ++l) rsum[l] = (float)rowsum[(size_t)l * T + t];
     const float *sce = scales + (size_t)done.e * N;
     const float *zpe = zps + (size_t)done.e * N;
-    float *orow = out + (size_t)t * N;
-    const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
-                     ((reinterpret_cast<uintptr_t>(sce) & 15) == 0) && ((reinterpret_cast<uintptr_t>(zpe) & 15) == 0);
+    const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & (out_kind == 0 ? 15 : 7)) == 0);
+    const bool vec_sz = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(sce) & 15) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(zpe) & 15) == 0);
 #pragma unroll
     for (int j = 0; j < NF; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int n = n0 + j * 32 + 8 * q + 4 * g;
             if (n >= N) continue;
-            if (vec) {
-                const v4f s4 = *reinterpret_cast<const v4f *>(sce + n);
-                const v4f z4 = *reinterpret_cast<const v4f *>(zpe + n);
-                float o[4];
+            float s4[4], z4[4];
+            if (vec_sz) {
+                const v4f sv = *reinterpret_cast<const v4f *>(sce + n);
+                const v4f zv = *reinterpret_cast<const v4f *>(zpe + n);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float tot = 0.0f;
-#pragma unroll
-                    for (int l = L - 1; l >= 0; --l)
-                        tot = fmaf(tot, 256.0f, fmaf(-z4[c], rsum[l], (float)acc[l][j][4 * q + c]));
-                    o[c] = (tot * d) * s4[c];
-                }
-                *reinterpret_cast<v4f *>(orow + n) = v4f{o[0], o[1], o[2], o[3]};
+                for (int c = 0; c < 4; ++c) { s4[c] = sv[c]; z4[c] = zv[c]; }
             } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    if (n + c >= N) continue;
-                    float tot = 0.0f;
-#pragma unroll
-                    for (int l = L - 1; l >= 0; --l)
-                        tot = fmaf(tot, 256.0f, fmaf(-zpe[n + c], rsum[l], (float)acc[l][j][4 * q + c]));
-                    orow[n + c] = (tot * d) * sce[n + c];
+                    s4[c] = (n + c < N) ? sce[n + c] : 0.0f;
+                    z4[c] = (n + c < N) ? zpe[n + c] : 0.0f;
                 }
             }
+            float o[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float tot = 0.0f;
+#pragma unroll
+                for (int l = L - 1; l >= 0; --l)
+                    tot = fmaf(tot, 256.0f, fmaf(-z4[c], rsum[l], (float)acc[l][j][4 * q + c]));
+                o[c] = (tot * d) * s4[c];
+            }
+            store_out4(out, out_kind, (size_t)t * N, n, N, vec, o);
         }
   }
 #endif

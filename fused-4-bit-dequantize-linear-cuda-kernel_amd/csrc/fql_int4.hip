@@ -108,9 +108,12 @@ inline int compute_units()
     return cached;
 }
 
+inline int dtype_bytes(int dt) { return dt == FQL_DTYPE_F32 ? 4 : 2; }
+
 template <int L>
-int launch_act_quant(const float *x, const int32_t *gather, int n_src, const Workspace &w, int T, int K, int Kp,
-                     int MBT, float *out, int N, const int32_t *tpe, const int32_t *offs, int E, hipStream_t st)
+int launch_act_quant(const void *x, int in_dtype, const int32_t *gather, int n_src, const Workspace &w, int T, int K,
+                     int Kp, int MBT, void *out, int out_dtype, int N, const int32_t *tpe, const int32_t *offs, int E,
+                     hipStream_t st)
 {
     // 8-row workgroups over the padded rows that can hold real rows (every expert's rows rounded up to 32), plus
     // (MoE entry point) the workgroups that zero the rows of `out` no expert covers
@@ -118,16 +121,22 @@ int launch_act_quant(const float *x, const int32_t *gather, int n_src, const Wor
     const int rblocks = mblocks * (FQL_MB / ACT_ROWS);
     const int zblocks = (tpe != nullptr && out != nullptr) ? (T + 255) / 256 : 0;
     const bool vec = (K % 16 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
-    auto kern = vec ? act_fused_kernel<L, true> : act_fused_kernel<L, false>;
+    void (*kern)(const void *, const int32_t *, int, float *, int32_t *, int8_t *, int, int, int, int, int, void *, int,
+                 int, const int32_t *, const int32_t *, int);
+    switch (in_dtype) {
+    case FQL_DTYPE_F16: kern = vec ? act_fused_kernel<L, true, 1> : act_fused_kernel<L, false, 1>; break;
+    case FQL_DTYPE_BF16: kern = vec ? act_fused_kernel<L, true, 2> : act_fused_kernel<L, false, 2>; break;
+    default: kern = vec ? act_fused_kernel<L, true, 0> : act_fused_kernel<L, false, 0>; break;
+    }
     hipLaunchKernelGGL(kern, dim3(rblocks + zblocks), dim3(256), 0, st, x, gather, n_src, w.delta, w.rowsum, w.limbs,
-                       T, K, Kp / FQL_KB, MBT, rblocks, out, N, tpe, offs, E);
+                       T, K, Kp / FQL_KB, MBT, rblocks, out, dtype_bytes(out_dtype), N, tpe, offs, E);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
 template <int L, int WM, int WN, int NF, int DEPTH, int BDEPTH>
 int launch_gemm_cfg(const Workspace &w, const uint8_t *packed, const float *scales, const float *zps,
-                    float *out, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT, int N,
-                    hipStream_t st)
+                    void *out, int out_dtype, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp,
+                    int MBT, int N, hipStream_t st)
 {
     using C = GemmCfg<L, WM, WN, NF, DEPTH, BDEPTH>;
     auto kern = gemm_i8_kernel<L, WM, WN, NF, DEPTH, BDEPTH>;
@@ -146,14 +155,14 @@ int launch_gemm_cfg(const Workspace &w, const uint8_t *packed, const float *scal
     const int cus = compute_units() * (C::NW >= 8 ? 1 : (C::NW == 4 ? 2 : 4));      // 2 waves per SIMD either way
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, w.limbs, w.delta, w.rowsum,
-                       packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots);
+                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
 template <int L, int NF, int KG, int DEPTH, int BDEPTH, int OCC>
-int launch_rows32_cfg(const Workspace &w, const uint8_t *packed, const float *scales, const float *zps, float *out,
-                      const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT, int N,
-                      hipStream_t st)
+int launch_rows32_cfg(const Workspace &w, const uint8_t *packed, const float *scales, const float *zps, void *out,
+                      int out_dtype, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT,
+                      int N, hipStream_t st)
 {
     using C = Rows32Cfg<L, NF, KG, DEPTH, BDEPTH, OCC>;
     auto kern = gemm_i8_rows32_kernel<L, NF, KG, DEPTH, BDEPTH, OCC>;
@@ -171,25 +180,26 @@ int launch_rows32_cfg(const Workspace &w, const uint8_t *packed, const float *sc
     const int cus = compute_units() * C::WG_PER_CU;          // persistent: WG_PER_CU 8-wave workgroups per CU
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, w.limbs, w.delta, w.rowsum,
-                       packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots);
+                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
 template <int L>
 int launch_gemm(int cfg, const Workspace &w, const uint8_t *packed, const float *scales, const float *zps,
-                float *out, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT, int N,
-                hipStream_t st)
+                void *out, int out_dtype, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT,
+                int N, hipStream_t st)
 {
     switch (cfg) {
 #define X(id, wm, wn, nf, d, bp)                                                                                  \
     case id:                                                                                                      \
-        return launch_gemm_cfg<L, wm, wn, nf, d, bp>(w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, st);
+        return launch_gemm_cfg<L, wm, wn, nf, d, bp>(w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, \
+                                                     MBT, N, st);
         FQL_CFG_LIST(X)
 #undef X
 #define R(i, nf, kg, d, bd, occ)                                                                                   \
     case 100 + i:                                                                                                 \
-        return launch_rows32_cfg<L, nf, kg, d, bd, occ>(w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, \
-                                                        st);
+        return launch_rows32_cfg<L, nf, kg, d, bd, occ>(w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, \
+                                                        Kp, MBT, N, st);
         FQL_ROWS32_LIST(R)
 #undef R
     default: return FQL_ERR_BAD_SHAPE;
@@ -234,31 +244,31 @@ inline int choose_cfg(int L, int E, int T, int K, int N, bool grouped)
     return best;
 }
 
-int run_mfma(int L, const float *x, const int32_t *gather, int n_src, const uint8_t *packed, const float *scales, const float *zps, float *out,
-             const int32_t *tpe, const int32_t *offs, int E, int T, int K, int N, void *workspace,
-             size_t workspace_bytes, hipStream_t st)
+int run_mfma(int L, const void *x, int in_dtype, const int32_t *gather, int n_src, const uint8_t *packed,
+             const float *scales, const float *zps, void *out, int out_dtype, const int32_t *tpe, const int32_t *offs,
+             int E, int T, int K, int N, void *workspace, size_t workspace_bytes, hipStream_t st)
 {
     const int Kp = padded_k(K);
     const int MBT = row_blocks(T, E);
     if (workspace == nullptr || !aligned16(workspace)) return FQL_ERR_WORKSPACE;
     const Workspace w = carve(workspace, L, T, E, Kp);
     if (workspace_bytes < w.bytes) return FQL_ERR_WORKSPACE;
-    float *zero_out = (tpe != nullptr) ? out : nullptr;
+    void *zero_out = (tpe != nullptr) ? out : nullptr;
     const int cfg = choose_cfg(L, E, T, K, N, tpe != nullptr);
     int rc;
     if (L == 1) {
-        rc = launch_act_quant<1>(x, gather, n_src, w, T, K, Kp, MBT, zero_out, N, tpe, offs, E, st);
+        rc = launch_act_quant<1>(x, in_dtype, gather, n_src, w, T, K, Kp, MBT, zero_out, out_dtype, N, tpe, offs, E, st);
         if (rc != FQL_OK) return rc;
-        return launch_gemm<1>(cfg, w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, st);
+        return launch_gemm<1>(cfg, w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, st);
     }
     if (L == 2) {
-        rc = launch_act_quant<2>(x, gather, n_src, w, T, K, Kp, MBT, zero_out, N, tpe, offs, E, st);
+        rc = launch_act_quant<2>(x, in_dtype, gather, n_src, w, T, K, Kp, MBT, zero_out, out_dtype, N, tpe, offs, E, st);
         if (rc != FQL_OK) return rc;
-        return launch_gemm<2>(cfg, w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, st);
+        return launch_gemm<2>(cfg, w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, st);
     }
-    rc = launch_act_quant<3>(x, gather, n_src, w, T, K, Kp, MBT, zero_out, N, tpe, offs, E, st);
+    rc = launch_act_quant<3>(x, in_dtype, gather, n_src, w, T, K, Kp, MBT, zero_out, out_dtype, N, tpe, offs, E, st);
     if (rc != FQL_OK) return rc;
-    return launch_gemm<3>(cfg, w, packed, scales, zps, out, tpe, offs, E, T, K, Kp, MBT, N, st);
+    return launch_gemm<3>(cfg, w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, st);
 }
 
 int run_generic(const float *x, const uint8_t *packed, const float *scales, const float *zps, float *out,
@@ -308,6 +318,7 @@ const char *fql_error_string(int code)
     case FQL_ERR_WORKSPACE: return "workspace is NULL, not 16-byte aligned, or smaller than *_workspace_bytes()";
     case FQL_ERR_LAUNCH: return "kernel launch failed (hipGetLastError)";
     case FQL_ERR_BAD_PRECISION: return "precision must be FQL_PRECISION_DEFAULT, _INT8 (1), _FAST (2) or _EXACT (3)";
+    case FQL_ERR_DTYPE: return "element type not supported on this path (16-bit input / output exists on the MFMA path only)";
     case FQL_ERR_ALIGNMENT: return "tensor base pointer not aligned as documented";
     default: return "unknown error code";
     }
@@ -359,7 +370,8 @@ int fql_linear_fwd_f32(const float *x, const uint8_t *packed, const float *scale
         return run_generic(x, packed, scales, zps, out, nullptr, nullptr, 1, B, K, N, st);
     }
     if (mfma_eligible(L, B, 1, K, N, packed))
-        return run_mfma(L, x, nullptr, 0, packed, scales, zps, out, nullptr, nullptr, 1, B, K, N, workspace, workspace_bytes, st);
+        return run_mfma(L, x, FQL_DTYPE_F32, nullptr, 0, packed, scales, zps, out, FQL_DTYPE_F32, nullptr, nullptr, 1, B, K, N,
+                        workspace, workspace_bytes, st);
     return run_generic(x, packed, scales, zps, out, nullptr, nullptr, 1, B, K, N, st);
 }
 
@@ -381,8 +393,8 @@ static int moe_entry(const uint8_t *packed, const float *scales, const float *zp
     if (!packed || !scales || !zps || !inputs || !tokens_per_expert || !input_offsets) return FQL_ERR_NULL_POINTER;
     if (E > 65535) return FQL_ERR_BAD_SHAPE;
     if (mfma_eligible(L, T, E, K, N, packed))
-        return run_mfma(L, inputs, row_index, n_src, packed, scales, zps, out, tokens_per_expert, input_offsets, E, T,
-                        K, N, workspace, workspace_bytes, st);
+        return run_mfma(L, inputs, FQL_DTYPE_F32, row_index, n_src, packed, scales, zps, out, FQL_DTYPE_F32,
+                        tokens_per_expert, input_offsets, E, T, K, N, workspace, workspace_bytes, st);
     if (row_index != nullptr) return FQL_ERR_ALIGNMENT;     // the fused gather exists on the MFMA path only
     return run_generic(inputs, packed, scales, zps, out, tokens_per_expert, input_offsets, E, T, K, N, st);
 }
@@ -403,6 +415,55 @@ int fql_moe_gather_fwd_f32(const uint8_t *packed, const float *scales, const flo
     if (!row_index) return FQL_ERR_NULL_POINTER;
     return moe_entry(packed, scales, zps, tokens, row_index, n_tokens, tokens_per_expert, input_offsets, out, E, T, K,
                      N, precision, workspace, workspace_bytes, stream);
+}
+
+static bool valid_dtype(int dt) { return dt == FQL_DTYPE_F32 || dt == FQL_DTYPE_F16 || dt == FQL_DTYPE_BF16; }
+
+int fql_native_dtype_supported(int rows, int E, int K, int N, int precision, const void *packed, int grouped)
+{
+    const int L = limbs_of(precision);
+    if (L < 0 || rows <= 0 || E <= 0) return 0;
+    if (!grouped && rows <= 4) return 0;                     // the GEMV path is float32 only
+    return mfma_eligible(L, rows, E, K, N, static_cast<const uint8_t *>(packed)) ? 1 : 0;
+}
+
+int fql_linear_fwd(const void *x, int in_dtype, const uint8_t *packed, const float *scales, const float *zps, void *out,
+                   int out_dtype, int B, int K, int N, int precision, void *workspace, size_t workspace_bytes,
+                   void *stream)
+{
+    if (in_dtype == FQL_DTYPE_F32 && out_dtype == FQL_DTYPE_F32)
+        return fql_linear_fwd_f32(static_cast<const float *>(x), packed, scales, zps, static_cast<float *>(out), B, K, N,
+                                  precision, workspace, workspace_bytes, stream);
+    const int L = limbs_of(precision);
+    if (L < 0) return FQL_ERR_BAD_PRECISION;
+    if (!valid_dtype(in_dtype) || !valid_dtype(out_dtype)) return FQL_ERR_DTYPE;
+    if (B < 0 || K < 0 || N < 0) return FQL_ERR_BAD_SHAPE;
+    if (K & 1) return FQL_ERR_ODD_K;
+    if (B == 0 || N == 0) return FQL_OK;
+    if (!x || !packed || !scales || !zps || !out) return FQL_ERR_NULL_POINTER;
+    if (B <= 4 || !mfma_eligible(L, B, 1, K, N, packed)) return FQL_ERR_DTYPE;   // 16-bit I/O exists on the MFMA path only
+    return run_mfma(L, x, in_dtype, nullptr, 0, packed, scales, zps, out, out_dtype, nullptr, nullptr, 1, B, K, N,
+                    workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int fql_moe_fwd(const uint8_t *packed, const float *scales, const float *zps, const void *inputs, int in_dtype,
+                const int32_t *tokens_per_expert, const int32_t *input_offsets, void *out, int out_dtype, int E, int T,
+                int K, int N, int precision, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (in_dtype == FQL_DTYPE_F32 && out_dtype == FQL_DTYPE_F32)
+        return fql_moe_fwd_f32(packed, scales, zps, static_cast<const float *>(inputs), tokens_per_expert, input_offsets,
+                               static_cast<float *>(out), E, T, K, N, precision, workspace, workspace_bytes, stream);
+    const int L = limbs_of(precision);
+    if (L < 0) return FQL_ERR_BAD_PRECISION;
+    if (!valid_dtype(in_dtype) || !valid_dtype(out_dtype)) return FQL_ERR_DTYPE;
+    if (E <= 0 || T < 0 || K <= 0 || N < 0) return FQL_ERR_BAD_SHAPE;
+    if (K & 1) return FQL_ERR_ODD_K;
+    if (T == 0 || N == 0) return FQL_OK;
+    if (!packed || !scales || !zps || !inputs || !tokens_per_expert || !input_offsets || !out) return FQL_ERR_NULL_POINTER;
+    if (E > 65535) return FQL_ERR_BAD_SHAPE;
+    if (!mfma_eligible(L, T, E, K, N, packed)) return FQL_ERR_DTYPE;
+    return run_mfma(L, inputs, in_dtype, nullptr, 0, packed, scales, zps, out, out_dtype, tokens_per_expert,
+                    input_offsets, E, T, K, N, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 int fql_unpack_u8(const uint8_t *packed, uint8_t *q, size_t nbytes, void *stream)
@@ -452,9 +513,9 @@ int fql_act_quant_f32(const float *x, int8_t *limbs, float *delta, int32_t *rows
     w.limbs = limbs; w.delta = delta; w.rowsum = rowsum; w.bytes = 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int Kp = padded_k(K), MBT = row_blocks(T, E);
-    if (L == 1) return launch_act_quant<1>(x, nullptr, 0, w, T, K, Kp, MBT, nullptr, 0, tokens_per_expert, input_offsets, E, st);
-    if (L == 2) return launch_act_quant<2>(x, nullptr, 0, w, T, K, Kp, MBT, nullptr, 0, tokens_per_expert, input_offsets, E, st);
-    return launch_act_quant<3>(x, nullptr, 0, w, T, K, Kp, MBT, nullptr, 0, tokens_per_expert, input_offsets, E, st);
+    if (L == 1) return launch_act_quant<1>(x, FQL_DTYPE_F32, nullptr, 0, w, T, K, Kp, MBT, nullptr, FQL_DTYPE_F32, 0, tokens_per_expert, input_offsets, E, st);
+    if (L == 2) return launch_act_quant<2>(x, FQL_DTYPE_F32, nullptr, 0, w, T, K, Kp, MBT, nullptr, FQL_DTYPE_F32, 0, tokens_per_expert, input_offsets, E, st);
+    return launch_act_quant<3>(x, FQL_DTYPE_F32, nullptr, 0, w, T, K, Kp, MBT, nullptr, FQL_DTYPE_F32, 0, tokens_per_expert, input_offsets, E, st);
 }
 
 int fql_quantize_rows_f32(const float *w, uint8_t *packed, float *scales, float *zps, int N, int K, void *stream)
@@ -507,10 +568,10 @@ static int gemm_i8_entry(int cfg, const int8_t *limbs, const float *delta, const
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int Kp = padded_k(K), MBT = row_blocks(T, E);
     if (L == 1)
-        return launch_gemm<1>(cfg, w, packed, scales, zps, out, tokens_per_expert, input_offsets, E, T, K, Kp, MBT, N, st);
+        return launch_gemm<1>(cfg, w, packed, scales, zps, out, FQL_DTYPE_F32, tokens_per_expert, input_offsets, E, T, K, Kp, MBT, N, st);
     if (L == 2)
-        return launch_gemm<2>(cfg, w, packed, scales, zps, out, tokens_per_expert, input_offsets, E, T, K, Kp, MBT, N, st);
-    return launch_gemm<3>(cfg, w, packed, scales, zps, out, tokens_per_expert, input_offsets, E, T, K, Kp, MBT, N, st);
+        return launch_gemm<2>(cfg, w, packed, scales, zps, out, FQL_DTYPE_F32, tokens_per_expert, input_offsets, E, T, K, Kp, MBT, N, st);
+    return launch_gemm<3>(cfg, w, packed, scales, zps, out, FQL_DTYPE_F32, tokens_per_expert, input_offsets, E, T, K, Kp, MBT, N, st);
 }
 
 int fql_gemm_i8_f32(const int8_t *limbs, const float *delta, const int32_t *rowsum, const uint8_t *packed,

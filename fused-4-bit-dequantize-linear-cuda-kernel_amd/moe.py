@@ -112,9 +112,8 @@ class QuantizedMoEExpert(nn.Module):
             return torch.empty(0, self.out_features, device=x.device, dtype=torch.float16)
         if x.is_cuda:
             from . import ops
-            y = ops.linear_forward(x.float().contiguous(), self.packed_weights, self.scales, self.zero_points,
-                                   precision=self.precision)
-            return y.to(x.dtype)
+            return ops.linear_forward_any(x.contiguous(), self.packed_weights, self.scales, self.zero_points,
+                                          precision=self.precision)          # in x's dtype (:70-72)
         w = dequantize_weights(self.packed_weights, self.scales, self.zero_points)
         return x @ w.T.to(x.dtype)
 
@@ -160,11 +159,15 @@ class QuantizedMoE(nn.Module):
         dev = expert_inputs[0].device
         counts = [int(x.shape[0]) for x in expert_inputs]
         packed, scales, zps = self._stack(dev)
-        grouped = torch.cat([x.float() for x in expert_inputs], dim=0).contiguous()
+        dtypes = {x.dtype for x in expert_inputs}
+        common = dtypes.pop() if len(dtypes) == 1 else torch.float32      # mixed dtypes: compute once in float32
+        if common not in (torch.float32, torch.float16, torch.bfloat16):
+            common = torch.float32
+        grouped = torch.cat([x.to(common) for x in expert_inputs], dim=0).contiguous()
         tpe = torch.tensor(counts, dtype=torch.int32)
         offs = torch.cumsum(tpe, 0, dtype=torch.int32) - tpe
-        out = ops.moe_forward(packed, scales, zps, grouped, None, tpe.to(dev, non_blocking=True),
-                              offs.to(dev, non_blocking=True), precision=self.precision) \
+        out = ops.moe_forward_any(packed, scales, zps, grouped, None, tpe.to(dev, non_blocking=True),
+                                  offs.to(dev, non_blocking=True), precision=self.precision) \
             if grouped.shape[0] else grouped.new_zeros((0, self.ffn_dim))
         outs, o = [], 0
         for x, c in zip(expert_inputs, counts):

@@ -138,6 +138,86 @@ def moe_forward(packed_weights, scales, zero_points, inputs, expert_ids, tokens_
     return out
 
 
+_DTYPES = {torch.float32: _native.DTYPE_F32, torch.float16: _native.DTYPE_F16, torch.bfloat16: _native.DTYPE_BF16}
+
+
+def linear_forward_any(input, packed_weights, scales, zero_points, precision="default", out_dtype=None):
+    """``linear_forward`` for float32 / float16 / bfloat16 activations, output in ``out_dtype`` (default: the
+    input's).  Equal bit for bit to ``linear_forward(input.float()).to(out_dtype)``; on the MFMA path the two
+    conversion passes are fused into the kernels, elsewhere torch converts."""
+    out_dtype = input.dtype if out_dtype is None else out_dtype
+    if input.dtype not in _DTYPES or out_dtype not in _DTYPES:
+        raise RuntimeError("activations and outputs must be float32, float16 or bfloat16")
+    if input.dtype == torch.float32 and out_dtype == torch.float32:
+        return linear_forward(input, packed_weights, scales, zero_points, precision=precision)
+    x2 = input.unsqueeze(0) if input.dim() == 1 else input
+    prec = _precision(precision)
+    L = _native.lib()
+    native = (x2.is_cuda and x2.dim() == 2 and x2.is_contiguous() and packed_weights.is_cuda
+              and packed_weights.dtype == torch.uint8 and packed_weights.dim() == 2 and packed_weights.is_contiguous()
+              and packed_weights.shape[1] * 2 == x2.shape[1]
+              and L.fql_native_dtype_supported(x2.shape[0], 1, x2.shape[1], packed_weights.shape[0], prec,
+                                               packed_weights.data_ptr(), 0) == 1)
+    if not native:
+        return linear_forward(input.float().contiguous(), packed_weights, scales, zero_points,
+                              precision=precision).to(out_dtype)
+    B, K = x2.shape
+    N = packed_weights.shape[0]
+    dev = x2.device
+    if scales.numel() != N or zero_points.numel() != N or scales.dtype != torch.float32 or zero_points.dtype != torch.float32:
+        raise RuntimeError("scales and zero_points must be float32 with output_dim elements")
+    scales, zero_points = scales.contiguous(), zero_points.contiguous()
+    out = torch.empty((B, N), dtype=out_dtype, device=dev)
+    with torch.cuda.device(dev):
+        ws, ws_ptr = _workspace(L.fql_linear_workspace_bytes(B, K, N, prec), dev)
+        rc = L.fql_linear_fwd(x2.data_ptr(), _DTYPES[x2.dtype], packed_weights.data_ptr(), scales.data_ptr(),
+                              zero_points.data_ptr(), out.data_ptr(), _DTYPES[out_dtype], B, K, N, prec,
+                              ws_ptr, 0 if ws is None else ws.numel(), _stream_ptr(dev))
+    _native.check(rc, "fql_linear_fwd")
+    return out.squeeze(0) if input.dim() == 1 else out
+
+
+def moe_forward_any(packed_weights, scales, zero_points, inputs, expert_ids, tokens_per_expert, input_offsets,
+                    precision="default", out_dtype=None):
+    """``moe_forward`` for float32 / float16 / bfloat16 rows (the reference's MoE benches feed float16,
+    benchmark/moe_grouped_gemm/moe_int4_module.py:161-165), output in ``out_dtype`` (default: the input's).
+    Equal bit for bit to ``moe_forward(inputs.float()).to(out_dtype)``."""
+    out_dtype = inputs.dtype if out_dtype is None else out_dtype
+    if inputs.dtype not in _DTYPES or out_dtype not in _DTYPES:
+        raise RuntimeError("activations and outputs must be float32, float16 or bfloat16")
+    if inputs.dtype == torch.float32 and out_dtype == torch.float32:
+        return moe_forward(packed_weights, scales, zero_points, inputs, expert_ids, tokens_per_expert, input_offsets,
+                           precision=precision)
+    prec = _precision(precision)
+    L = _native.lib()
+    ok = (inputs.is_cuda and inputs.dim() == 2 and packed_weights.is_cuda and packed_weights.dim() == 3
+          and packed_weights.dtype == torch.uint8 and packed_weights.shape[2] * 2 == inputs.shape[1])
+    native = ok and L.fql_native_dtype_supported(inputs.shape[0], packed_weights.shape[0], inputs.shape[1],
+                                                 packed_weights.shape[1], prec, packed_weights.data_ptr(), 1) == 1
+    if not native:
+        return moe_forward(packed_weights, scales, zero_points, inputs.float().contiguous(), expert_ids,
+                           tokens_per_expert, input_offsets, precision=precision).to(out_dtype)
+    E, N, _ = packed_weights.shape
+    T, K = inputs.shape
+    if tuple(scales.shape) != (E, N) or tuple(zero_points.shape) != (E, N):
+        raise RuntimeError("scales and zero_points must be [num_experts, ffn_dim]")
+    if tokens_per_expert.numel() != E or input_offsets.numel() != E:
+        raise RuntimeError("tokens_per_expert and input_offsets must have num_experts elements")
+    dev = inputs.device
+    inputs = inputs.contiguous()
+    packed_weights, scales, zero_points = packed_weights.contiguous(), scales.contiguous(), zero_points.contiguous()
+    tpe = tokens_per_expert.to(device=dev, dtype=torch.int32).contiguous()
+    offs = input_offsets.to(device=dev, dtype=torch.int32).contiguous()
+    out = torch.empty((T, N), dtype=out_dtype, device=dev)
+    with torch.cuda.device(dev):
+        ws, ws_ptr = _workspace(L.fql_moe_workspace_bytes(E, T, K, N, prec), dev)
+        rc = L.fql_moe_fwd(packed_weights.data_ptr(), scales.data_ptr(), zero_points.data_ptr(), inputs.data_ptr(),
+                           _DTYPES[inputs.dtype], tpe.data_ptr(), offs.data_ptr(), out.data_ptr(), _DTYPES[out_dtype],
+                           E, T, K, N, prec, ws_ptr, 0 if ws is None else ws.numel(), _stream_ptr(dev))
+    _native.check(rc, "fql_moe_fwd")
+    return out
+
+
 def moe_gather_forward(packed_weights, scales, zero_points, tokens, row_index, tokens_per_expert,
                        input_offsets, precision="default"):
     """Grouped per-expert INT4 GEMM with the dispatch gather fused in: grouped row t = tokens[row_index[t]].

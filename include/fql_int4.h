@@ -54,6 +54,7 @@ extern "C" {
 #define FQL_ERR_LAUNCH (-5)         /* hipGetLastError() reported a launch failure                 */
 #define FQL_ERR_BAD_PRECISION (-6)  /* precision not one of FQL_PRECISION_*                        */
 #define FQL_ERR_ALIGNMENT (-7)      /* a tensor base pointer is not aligned as documented          */
+#define FQL_ERR_DTYPE (-8)          /* element type not supported on the path this shape takes     */
 
 /* Activation precision of the MFMA path.  Weights are always exact (4-bit integers).
  * Activations are split per row into signed 8-bit limbs of a fixed-point value; the integer
@@ -71,6 +72,14 @@ extern "C" {
 #define FQL_PRECISION_INT8 1
 #define FQL_PRECISION_FAST 2
 #define FQL_PRECISION_EXACT 3
+
+/* Element types of activations and outputs for the dtype-generic entry points (fql_linear_fwd / fql_moe_fwd).
+ * 16-bit inputs are widened exactly; outputs are rounded to nearest even from the float32 result, i.e. the
+ * result equals `fql_*_fwd_f32(x.float()).to(dtype)` bit for bit, without the two conversion passes
+ * (reference: benchmark/moe_grouped_gemm/moe_int4_module.py:70-72 runs its experts in the dtype of x). */
+#define FQL_DTYPE_F32 0
+#define FQL_DTYPE_F16 1
+#define FQL_DTYPE_BF16 2
 
 FQL_API int fql_version(void);
 FQL_API const char *fql_error_string(int code);
@@ -182,6 +191,25 @@ FQL_API int fql_gemm_i8_f32(const int8_t *limbs, const float *delta, const int32
                             const uint8_t *packed, const float *scales, const float *zps,
                             const int32_t *tokens_per_expert, const int32_t *input_offsets,
                             float *out, int E, int T, int K, int N, int precision, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Dtype-generic forms of fql_linear_fwd_f32 / fql_moe_fwd_f32 (float16 / bfloat16
+ * activations and outputs, as the reference's MoE benches feed them).  Same arguments plus the element
+ * types; (F32, F32) forwards to the float32 entry points.  16-bit I/O exists on the MFMA path only
+ * (more than 4 rows, K % 32 == 0, 16-byte aligned packed weights): other shapes return FQL_ERR_DTYPE and
+ * the caller converts.  fql_native_dtype_supported answers that question without launching anything.
+ * ------------------------------------------------------------------------------------- */
+FQL_API int fql_native_dtype_supported(int rows, int E, int K, int N, int precision, const void *packed,
+                                       int grouped);
+
+FQL_API int fql_linear_fwd(const void *x, int in_dtype, const uint8_t *packed, const float *scales,
+                           const float *zps, void *out, int out_dtype, int B, int K, int N, int precision,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
+FQL_API int fql_moe_fwd(const uint8_t *packed, const float *scales, const float *zps, const void *inputs,
+                        int in_dtype, const int32_t *tokens_per_expert, const int32_t *input_offsets,
+                        void *out, int out_dtype, int E, int T, int K, int N, int precision,
+                        void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -450,6 +450,57 @@ def test_fused_dispatch_gather_equals_materialised(fq):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("prec", ["exact", "fast"])
+def test_native_16bit_io_equals_converted_float32(fq, dtype, prec):
+    """float16 / bfloat16 activations in and out.  The kernels widen the inputs exactly and round
+    the float32 result to nearest even, so the native path must equal float32-path(x.float()).to(dtype) bit for
+    bit -- linear (wide tiles, ragged N), grouped MoE with an empty expert, uncovered rows and few-row groups."""
+    from fused_int4_amd import ops
+    rng = np.random.default_rng(11)
+    # linear, MFMA path
+    x, p, s, z = make_problem(200, 512, 70, 5)
+    xd = dev(x).to(dtype)
+    got = ops.linear_forward_any(xd, dev(p), dev(s), dev(z), precision=prec)
+    want = ops.linear_forward(xd.float(), dev(p), dev(s), dev(z), precision=prec).to(dtype)
+    assert got.dtype == dtype and torch.equal(got, want)
+    # float32 in, 16-bit out and the reverse
+    got = ops.linear_forward_any(dev(x), dev(p), dev(s), dev(z), precision=prec, out_dtype=dtype)
+    assert torch.equal(got, ops.linear_forward(dev(x), dev(p), dev(s), dev(z), precision=prec).to(dtype))
+    got = ops.linear_forward_any(xd, dev(p), dev(s), dev(z), precision=prec, out_dtype=torch.float32)
+    assert torch.equal(got, ops.linear_forward(xd.float(), dev(p), dev(s), dev(z), precision=prec))
+    # B <= 4 and K % 32 != 0 fall back to conversion, same contract
+    x1, p1, s1, z1 = make_problem(64, 96, 3, 6)
+    got = ops.linear_forward_any(dev(x1).to(dtype), dev(p1), dev(s1), dev(z1), precision=prec)
+    assert torch.equal(got, ops.linear_forward(dev(x1).to(dtype).float(), dev(p1), dev(s1), dev(z1), precision=prec).to(dtype))
+    # grouped, with an empty expert, a 3-row gap of uncovered rows; wide tiles and the short-row-group kernel
+    for counts in ([40, 0, 133, 20], [3, 7, 0, 30, 1, 12, 9, 2]):
+        E = len(counts)
+        P, S, Z, xm, cnt, offs = make_moe(E, 264, 256, counts, 17 + E, gap_rows=3)
+        xmd = dev(xm).to(dtype)
+        got = ops.moe_forward_any(dev(P), dev(S), dev(Z), xmd, None, dev(cnt), dev(offs), precision=prec)
+        want = ops.moe_forward(dev(P), dev(S), dev(Z), xmd.float(), None, dev(cnt), dev(offs), precision=prec).to(dtype)
+        assert got.dtype == dtype and torch.equal(got, want)
+        assert (got[-3:] == 0).all()
+
+
+def test_quantized_moe_module_keeps_16bit_inputs_native(fq):
+    """QuantizedMoE fed float16 rows (as the reference's benches do) returns float16 and matches the CPU oracle."""
+    torch.manual_seed(3)
+    E, K, N = 4, 128, 96
+    ws = [torch.randn(N, K) * 0.02 for _ in range(E)]
+    moe = fq.QuantizedMoE.from_fp16_weights([w.half() for w in ws]).cuda()
+    xs = [torch.randn(m, K).half() for m in (9, 0, 33, 5)]
+    outs = moe([x.cuda() for x in xs])
+    for e, (x, o) in enumerate(zip(xs, outs)):
+        assert o.dtype == torch.float16
+        if x.shape[0] == 0:
+            continue
+        p, s, z = (t.cpu().numpy() for t in (moe.experts[e].packed_weights, moe.experts[e].scales, moe.experts[e].zero_points))
+        ref = C.linear_f64acc(x.float().numpy(), p, s, z)
+        assert rel_fro(o.float().cpu().numpy(), ref) < 1e-3       # float16 rounding of the outputs
+
+
 def test_moe_clipping_of_bad_ranges(fq):
     """Offsets / counts that leave [0, T] are clipped on the device; nothing faults."""
     from fused_int4_amd import ops
