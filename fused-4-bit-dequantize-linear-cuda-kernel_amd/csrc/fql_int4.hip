@@ -10,6 +10,7 @@
 #include "fql_gemv.h"
 #include "fql_generic.h"
 #include "fql_quantize.h"
+#include "fql_routing.h"
 
 namespace {
 
@@ -464,6 +465,49 @@ int fql_moe_fwd(const uint8_t *packed, const float *scales, const float *zps, co
     if (!mfma_eligible(L, T, E, K, N, packed)) return FQL_ERR_DTYPE;
     return run_mfma(L, inputs, in_dtype, nullptr, 0, packed, scales, zps, out, out_dtype, tokens_per_expert,
                     input_offsets, E, T, K, N, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int fql_route_plan_i32(const int32_t *expert_of_slot, int n_slots, int top_k, int E, int32_t *counts,
+                       int32_t *offsets, int32_t *token_of_sorted, int32_t *pos_of_slot, void *stream)
+{
+    if (n_slots < 0 || top_k <= 0 || E <= 0 || E > ROUTE_MAX_EXPERTS) return FQL_ERR_BAD_SHAPE;
+    if (!counts || !offsets) return FQL_ERR_NULL_POINTER;
+    if (n_slots > 0 && (!expert_of_slot || !token_of_sorted || !pos_of_slot)) return FQL_ERR_NULL_POINTER;
+    const size_t lds = (size_t)(ROUTE_THREADS * E + E) * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(route_plan_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (ROUTE_THREADS * ROUTE_MAX_EXPERTS + ROUTE_MAX_EXPERTS) * (int)sizeof(int)) != hipSuccess)
+            return FQL_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(route_plan_kernel, dim3(1), dim3(ROUTE_THREADS), lds, static_cast<hipStream_t>(stream),
+                       expert_of_slot, n_slots, top_k, E, counts, offsets, token_of_sorted, pos_of_slot);
+    return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
+}
+
+int fql_combine_f32(const float *y, const int32_t *pos_of_slot, const float *weights, float *out, int T, int top_k,
+                    int N, int R, void *stream)
+{
+    if (T < 0 || top_k <= 0 || N < 0 || R < 0) return FQL_ERR_BAD_SHAPE;
+    if (T == 0 || N == 0) return FQL_OK;
+    if (!y || !pos_of_slot || !weights || !out || R == 0) return FQL_ERR_NULL_POINTER;
+    if (T > 65535) return FQL_ERR_BAD_SHAPE;                 // grid.y
+    hipLaunchKernelGGL(combine_kernel, dim3((N + 1023) / 1024, T), dim3(256), 0, static_cast<hipStream_t>(stream), y,
+                       pos_of_slot, weights, out, T, top_k, N, R);
+    return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
+}
+
+int fql_regroup_index_i32(const int32_t *recv_counts, int G, int EL, int32_t *tokens_per_expert,
+                          int32_t *input_offsets, int32_t *gather, int32_t *scatter, void *stream)
+{
+    if (G <= 0 || EL <= 0 || (size_t)G * EL > 8192) return FQL_ERR_BAD_SHAPE;
+    if (!recv_counts || !tokens_per_expert || !input_offsets || !gather || !scatter) return FQL_ERR_NULL_POINTER;
+    hipLaunchKernelGGL(regroup_index_kernel, dim3(1), dim3(256), (size_t)2 * G * EL * sizeof(int),
+                       static_cast<hipStream_t>(stream), recv_counts, G, EL, tokens_per_expert, input_offsets, gather,
+                       scatter);
+    return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
 int fql_unpack_u8(const uint8_t *packed, uint8_t *q, size_t nbytes, void *stream)

@@ -32,6 +32,12 @@ def _local_grouped_gemm(packed, scales, zps, precision):
     def fn(rows, tokens_per_expert, input_offsets):
         return ops.moe_forward(packed, scales, zps, rows, None, tokens_per_expert, input_offsets,
                                precision=precision)
+
+    def gather_fn(rows, row_index, tokens_per_expert, input_offsets):
+        """Same, grouped row i = rows[row_index[i]]: the regrouping copy is fused into the activation pre-pass."""
+        return ops.moe_gather_forward(packed, scales, zps, rows, row_index, tokens_per_expert, input_offsets,
+                                      precision=precision)
+    fn.gather = gather_fn
     return fn
 
 
@@ -68,8 +74,56 @@ class ExpertParallelMoE:
         per = tensor.shape[0] // world
         return tensor[rank * per:(rank + 1) * per]
 
+    def _forward_device(self, x, expert_indices, expert_weights):
+        """GPU path with the library's routing kernels: ONE launch plans the dispatch (stable sort by expert, counts,
+        offsets, gather and un-sort indices), the gathers are fused into the activation pre-pass, ONE launch
+        combines.  Same result as ``forward``'s torch formulation (bit for bit up to top_k = 2, where the
+        weighted sum has a single addition)."""
+        from . import ops
+        G, EL = self.world, self.experts_per_rank
+        top_k = expert_indices.shape[1]
+        dev = x.device
+        K = x.shape[1]
+        counts, offsets, token_of_sorted, pos_of_slot = ops.route_plan(expert_indices, self.num_experts)
+        fused_gather = hasattr(self.expert_fn, "gather") and K % 32 == 0 and x.dtype == torch.float32
+        if G == 1:
+            if fused_gather:
+                y_sorted = self.expert_fn.gather(x, token_of_sorted, counts, offsets)
+            else:
+                y_sorted = self.expert_fn(x.index_select(0, token_of_sorted.long()), counts, offsets)
+        else:
+            send_rows = x.index_select(0, token_of_sorted.long())
+            send_counts = counts.to(torch.int64)
+            recv_counts = torch.empty(G * EL, dtype=torch.int64, device=dev)
+            dist.all_to_all_single(recv_counts, send_counts, group=self.group)
+            recv_counts = recv_counts.view(G, EL)
+            # split sizes must be host integers for all_to_all_single: one small D2H copy per step
+            sizes = torch.stack([send_counts.view(G, EL).sum(1), recv_counts.sum(1)]).cpu()
+            in_splits, out_splits = sizes[0].tolist(), sizes[1].tolist()
+            R = sum(out_splits)
+            recv_rows = torch.empty((R, K), dtype=x.dtype, device=dev)
+            dist.all_to_all_single(recv_rows, send_rows, out_splits, in_splits, group=self.group)
+            # received order is (source rank, local expert); the GEMM wants (local expert, source rank)
+            tpe, offs, gather, scatter = ops.regroup_index(recv_counts, R)
+            if R == 0:
+                y_recv_order = torch.empty((0, self.out_features), dtype=torch.float32, device=dev)
+            elif fused_gather:
+                y_recv_order = self.expert_fn.gather(recv_rows, gather, tpe, offs).index_select(0, scatter.long())
+            else:
+                y_recv_order = self.expert_fn(recv_rows.index_select(0, gather.long()), tpe, offs).index_select(
+                    0, scatter.long())
+            y_sorted = torch.empty((send_rows.shape[0], y_recv_order.shape[1]), dtype=y_recv_order.dtype, device=dev)
+            dist.all_to_all_single(y_sorted, y_recv_order.contiguous(), in_splits, out_splits, group=self.group)
+            self.last_split = {"dispatch_rows_sent": in_splits, "dispatch_rows_received": out_splits}
+        if y_sorted.dtype == torch.float32 and x.shape[0] <= 65535:
+            return ops.combine(y_sorted, pos_of_slot, expert_weights)
+        y = y_sorted.index_select(0, pos_of_slot.long()).view(x.shape[0], top_k, -1)
+        return (y * expert_weights.unsqueeze(-1).to(y.dtype)).sum(dim=1)
+
     def forward(self, x: torch.Tensor, expert_indices: torch.Tensor, expert_weights: torch.Tensor) -> torch.Tensor:
         """x [t_local, K] float32, expert_indices / expert_weights [t_local, top_k] -> [t_local, N]."""
+        if x.is_cuda and self.num_experts <= 128 and x.shape[0] > 0:
+            return self._forward_device(x, expert_indices, expert_weights)
         G, EL = self.world, self.experts_per_rank
         top_k = expert_indices.shape[1]
         dev = x.device

@@ -254,6 +254,72 @@ def moe_gather_forward(packed_weights, scales, zero_points, tokens, row_index, t
     return out
 
 
+ROUTE_MAX_EXPERTS = 128
+
+
+def route_plan(expert_indices, num_experts):
+    """Stable sort of the (token, slot) pairs by expert in ONE launch (replaces argsort + bincount + cumsum +
+    index ops of routing.py:117-149).  ``expert_indices`` [T, top_k] integer, on the GPU.  Returns int32 device
+    tensors ``(tokens_per_expert [E], input_offsets [E], token_of_sorted [T*top_k], pos_of_slot [T*top_k])``."""
+    if not expert_indices.is_cuda or expert_indices.dim() != 2:
+        raise RuntimeError("expert_indices must be a CUDA [tokens, top_k] tensor")
+    if num_experts > ROUTE_MAX_EXPERTS:
+        raise RuntimeError(f"route_plan supports up to {ROUTE_MAX_EXPERTS} experts")
+    dev = expert_indices.device
+    T, top_k = expert_indices.shape
+    flat = expert_indices.reshape(-1).to(torch.int32).contiguous()
+    n = flat.numel()
+    counts = torch.empty(num_experts, dtype=torch.int32, device=dev)
+    offsets = torch.empty(num_experts, dtype=torch.int32, device=dev)
+    token_of_sorted = torch.empty(n, dtype=torch.int32, device=dev)
+    pos_of_slot = torch.empty(n, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _native.lib().fql_route_plan_i32(flat.data_ptr(), n, top_k, num_experts, counts.data_ptr(),
+                                              offsets.data_ptr(), token_of_sorted.data_ptr(), pos_of_slot.data_ptr(),
+                                              _stream_ptr(dev))
+    _native.check(rc, "fql_route_plan_i32")
+    return counts, offsets, token_of_sorted, pos_of_slot
+
+
+def combine(y, pos_of_slot, expert_weights):
+    """out[t] = sum_k expert_weights[t, k] * y[pos_of_slot[t*top_k + k]] in one launch (routing.py:172-189)."""
+    if not y.is_cuda or y.dtype != torch.float32 or y.dim() != 2:
+        raise RuntimeError("y must be a CUDA float32 [rows, N] tensor")
+    T, top_k = expert_weights.shape
+    if T > 65535:
+        raise RuntimeError("combine handles up to 65535 tokens per call")
+    dev = y.device
+    y = y.contiguous()
+    w = expert_weights.to(device=dev, dtype=torch.float32).contiguous()
+    pos = pos_of_slot.to(device=dev, dtype=torch.int32).contiguous()
+    out = torch.empty((T, y.shape[1]), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _native.lib().fql_combine_f32(y.data_ptr(), pos.data_ptr(), w.data_ptr(), out.data_ptr(), T, top_k,
+                                           y.shape[1], y.shape[0], _stream_ptr(dev))
+    _native.check(rc, "fql_combine_f32")
+    return out
+
+
+def regroup_index(recv_counts, total_rows):
+    """Expert-parallel receive side: ``recv_counts`` [G, EL] (rows per source rank and local expert, in arrival
+    order), ``total_rows`` = their sum (the caller knows it on the host from the all-to-all split sizes) ->
+    ``(tokens_per_expert [EL], input_offsets [EL], gather [R], scatter [R])`` int32 device tensors, one launch."""
+    if not recv_counts.is_cuda or recv_counts.dim() != 2:
+        raise RuntimeError("recv_counts must be a CUDA [ranks, local_experts] tensor")
+    dev = recv_counts.device
+    G, EL = recv_counts.shape
+    cnt = recv_counts.to(torch.int32).contiguous()
+    tpe = torch.empty(EL, dtype=torch.int32, device=dev)
+    offs = torch.empty(EL, dtype=torch.int32, device=dev)
+    gather = torch.empty(max(total_rows, 1), dtype=torch.int32, device=dev)
+    scatter = torch.empty(max(total_rows, 1), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _native.lib().fql_regroup_index_i32(cnt.data_ptr(), G, EL, tpe.data_ptr(), offs.data_ptr(),
+                                                 gather.data_ptr(), scatter.data_ptr(), _stream_ptr(dev))
+    _native.check(rc, "fql_regroup_index_i32")
+    return tpe, offs, gather[:total_rows], scatter[:total_rows]
+
+
 def quantize_rows(weight_fp32):
     """GPU quantize_weights (python/quantize.py:38-124), bit-exact with the host arithmetic."""
     if not weight_fp32.is_cuda or weight_fp32.dtype != torch.float32 or weight_fp32.dim() != 2:

@@ -68,6 +68,16 @@ def balanced_routing(num_tokens: int, num_experts: int, top_k: int, device: str 
     return RoutingResult(idx.to(device), w.to(device), counts, offsets)
 
 
+def _plan_on_device(expert_indices: torch.Tensor, num_experts: int):
+    """One-launch plan (csrc/fql_routing.h) when the indices live on the GPU; None otherwise."""
+    if not expert_indices.is_cuda or expert_indices.numel() == 0:
+        return None
+    from . import ops
+    if num_experts > ops.ROUTE_MAX_EXPERTS:
+        return None
+    return ops.route_plan(expert_indices, num_experts)
+
+
 def _sort_by_expert(expert_indices: torch.Tensor):
     top_k = expert_indices.shape[1]
     flat_expert = expert_indices.reshape(-1)
@@ -83,6 +93,10 @@ def dispatch_grouped(x: torch.Tensor, expert_indices: torch.Tensor, num_experts:
 
     Returns ``(grouped [T*top_k, K], tokens_per_expert int32 [E], input_offsets int32 [E], inverse)``;
     nothing is read back to the host."""
+    plan = _plan_on_device(expert_indices, num_experts)
+    if plan is not None:
+        tpe, offs, token_of_sorted, pos_of_slot = plan
+        return x.index_select(0, token_of_sorted), tpe, offs, pos_of_slot
     _, token_of_slot, inverse = _sort_by_expert(expert_indices)
     grouped = x.index_select(0, token_of_slot)
     tpe = torch.bincount(expert_indices.reshape(-1), minlength=num_experts).to(torch.int32)
@@ -94,6 +108,10 @@ def dispatch_indices(expert_indices: torch.Tensor, num_experts: int):
     """Dispatch without moving any activation: ``(row_index int32 [T*top_k], tokens_per_expert,
     input_offsets, inverse)`` -- feed ``row_index`` to ``ops.moe_gather_forward`` and the gather is done
     inside the activation pre-pass."""
+    plan = _plan_on_device(expert_indices, num_experts)
+    if plan is not None:
+        tpe, offs, token_of_sorted, pos_of_slot = plan
+        return token_of_sorted, tpe, offs, pos_of_slot
     _, token_of_slot, inverse = _sort_by_expert(expert_indices)
     tpe = torch.bincount(expert_indices.reshape(-1), minlength=num_experts).to(torch.int32)
     offs = (torch.cumsum(tpe, 0) - tpe).to(torch.int32)
@@ -118,6 +136,9 @@ def create_expert_inputs(x: torch.Tensor, routing: RoutingResult, num_experts: i
 def combine_grouped(grouped_out: torch.Tensor, expert_weights: torch.Tensor, inverse: torch.Tensor,
                     top_k: int) -> torch.Tensor:
     """Un-sort ``[T*top_k, N]`` rows to ``[T, top_k, N]`` and take the routing-weighted sum."""
+    if grouped_out.is_cuda and grouped_out.dtype == torch.float32 and 0 < expert_weights.shape[0] <= 65535:
+        from . import ops
+        return ops.combine(grouped_out, inverse, expert_weights)         # one launch
     y = grouped_out.index_select(0, inverse)
     y = y.view(y.shape[0] // top_k, top_k, y.shape[-1])
     return (y * expert_weights.unsqueeze(-1).to(y.dtype)).sum(dim=1)

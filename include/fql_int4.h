@@ -211,6 +211,30 @@ FQL_API int fql_moe_fwd(const uint8_t *packed, const float *scales, const float 
                         void *out, int out_dtype, int E, int T, int K, int N, int precision,
                         void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Routing either side of the grouped GEMM, one launch each (reference: the torch index ops of
+ * benchmark/moe_grouped_gemm/routing.py:117-149 create_expert_inputs and :172-189 combine_expert_outputs).
+ *
+ * fql_route_plan_i32: stable counting sort of the n_slots = tokens * top_k (token, slot) pairs by expert id
+ *   (expert_of_slot = expert_indices flattened, ids clamped into [0, E), E <= 128).  Outputs, all int32 on the
+ *   device: counts[E] and offsets[E] (= tokens_per_expert / input_offsets), token_of_sorted[n_slots] (the
+ *   row_index of fql_moe_gather_fwd_f32) and pos_of_slot[n_slots] (where each slot's result row lands).
+ * fql_combine_f32: out[t][:] = sum_{k < top_k} weights[t][k] * y[pos_of_slot[t*top_k + k]][:], k ascending;
+ *   y is [R, N], out [T, N] (T <= 65535).
+ * fql_regroup_index_i32 (expert-parallel receive side): recv_counts[G][EL] rows per (source rank, local expert)
+ *   in arrival order -> tokens_per_expert[EL], input_offsets[EL], gather[R] (expert-major position -> received
+ *   row, the row_index of fql_moe_gather_fwd_f32) and scatter[R] (its inverse); G * EL <= 8192.
+ * ------------------------------------------------------------------------------------- */
+FQL_API int fql_route_plan_i32(const int32_t *expert_of_slot, int n_slots, int top_k, int E, int32_t *counts,
+                               int32_t *offsets, int32_t *token_of_sorted, int32_t *pos_of_slot,
+                               void *stream);
+
+FQL_API int fql_combine_f32(const float *y, const int32_t *pos_of_slot, const float *weights, float *out,
+                            int T, int top_k, int N, int R, void *stream);
+
+FQL_API int fql_regroup_index_i32(const int32_t *recv_counts, int G, int EL, int32_t *tokens_per_expert,
+                                  int32_t *input_offsets, int32_t *gather, int32_t *scatter, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -501,6 +501,82 @@ def test_quantized_moe_module_keeps_16bit_inputs_native(fq):
         assert rel_fro(o.float().cpu().numpy(), ref) < 1e-3       # float16 rounding of the outputs
 
 
+@pytest.mark.parametrize("T,E,top_k", [(16, 4, 2), (512, 8, 2), (333, 64, 6), (1, 3, 1), (4097, 128, 4)])
+def test_route_plan_is_the_stable_sort(fq, T, E, top_k):
+    """fql_route_plan_i32 == argsort(stable=True) / bincount / cumsum of routing.py:117-149, index for index."""
+    from fused_int4_amd import ops
+    g = torch.Generator().manual_seed(T * 31 + E)
+    idx = torch.stack([torch.randperm(E, generator=g)[:top_k] for _ in range(T)]) if top_k <= E else None
+    counts, offsets, token_of_sorted, pos_of_slot = ops.route_plan(idx.cuda(), E)
+    flat = idx.reshape(-1)
+    order = torch.argsort(flat, stable=True)
+    ref_counts = torch.bincount(flat, minlength=E)
+    assert torch.equal(counts.cpu().long(), ref_counts)
+    assert torch.equal(offsets.cpu().long(), torch.cumsum(ref_counts, 0) - ref_counts)
+    assert torch.equal(token_of_sorted.cpu().long(), order // top_k)
+    inverse = torch.empty_like(order)
+    inverse[order] = torch.arange(order.numel())
+    assert torch.equal(pos_of_slot.cpu().long(), inverse)
+
+
+@pytest.mark.parametrize("top_k", [1, 2, 4])
+def test_combine_kernel(fq, top_k):
+    from fused_int4_amd import ops
+    torch.manual_seed(5)
+    T, N = 37, 1004
+    y = torch.randn(T * top_k, N)
+    pos = torch.randperm(T * top_k).to(torch.int32)
+    w = torch.rand(T, top_k) + 0.1
+    got = ops.combine(y.cuda(), pos.cuda(), w.cuda()).cpu()
+    ref = (y[pos.long()].view(T, top_k, N) * w.unsqueeze(-1)).sum(dim=1)
+    if top_k <= 2:
+        assert torch.equal(got, ref)                         # one addition: no ordering freedom
+    else:
+        assert torch.allclose(got, ref, rtol=1e-6, atol=1e-6)
+    got = ops.combine(y[:, :1001].contiguous().cuda(), pos.cuda(), w.cuda()).cpu()      # N % 4 != 0
+    assert torch.allclose(got, (y[pos.long()][:, :1001].reshape(T, top_k, 1001) * w.unsqueeze(-1)).sum(dim=1), rtol=1e-6, atol=1e-6)
+
+
+def test_regroup_index(fq):
+    from fused_int4_amd import ops
+    torch.manual_seed(9)
+    G, EL = 4, 3
+    cnt = torch.randint(0, 7, (G, EL))
+    cnt[1, 2] = 0
+    R = int(cnt.sum())
+    tpe, offs, gather, scatter = ops.regroup_index(cnt.cuda(), R)
+    assert torch.equal(tpe.cpu().long(), cnt.sum(0))
+    assert torch.equal(offs.cpu().long(), torch.cumsum(cnt.sum(0), 0) - cnt.sum(0))
+    # received rows are labelled (s, e, i) in source-major order; expert-major order sorts by (e, s, i)
+    labels = [(s, e, i) for s in range(G) for e in range(EL) for i in range(int(cnt[s, e]))]
+    want = sorted(range(R), key=lambda r: (labels[r][1], labels[r][0], labels[r][2]))
+    assert gather.cpu().tolist() == want
+    assert scatter.cpu().long()[gather.cpu().long()].tolist() == list(range(R))
+
+
+def test_expert_parallel_wrapper_device_path_world1(fq):
+    """ExpertParallelMoE at world size 1 on the GPU (plan + fused gather + grouped GEMM + fused combine) equals
+    dispatch -> grouped GEMM -> un-sort -> weighted sum written with torch ops."""
+    from fused_int4_amd import ops, routing as R
+    from fused_int4_amd.ep import ExpertParallelMoE
+    E, N, K, T, top_k = 4, 136, 256, 50, 2
+    P, S, Z, _, _, _ = make_moe(E, N, K, [1] * E, 21)
+    route = R.simulate_routing(T, E, top_k, "skewed", "cuda", 7)
+    x = torch.randn(T, K, generator=torch.Generator().manual_seed(1)).cuda()
+    ep = ExpertParallelMoE(E, dev(P), dev(S), dev(Z))
+    got = ep(x, route.expert_indices, route.expert_weights)
+    flat = route.expert_indices.reshape(-1)
+    order = torch.argsort(flat, stable=True)
+    rows = x.index_select(0, order // top_k)
+    tpe = torch.bincount(flat, minlength=E).to(torch.int32)
+    offs = (torch.cumsum(tpe, 0) - tpe).to(torch.int32)
+    y = ops.moe_forward(dev(P), dev(S), dev(Z), rows, None, tpe, offs)
+    inverse = torch.empty_like(order)
+    inverse[order] = torch.arange(order.numel(), device=order.device)
+    want = (y.index_select(0, inverse).view(T, top_k, N) * route.expert_weights.unsqueeze(-1)).sum(dim=1)
+    assert torch.equal(got, want)
+
+
 def test_moe_clipping_of_bad_ranges(fq):
     """Offsets / counts that leave [0, T] are clipped on the device; nothing faults."""
     from fused_int4_amd import ops
