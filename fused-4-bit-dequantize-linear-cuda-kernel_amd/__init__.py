@@ -6,13 +6,13 @@ python/moe_int4_module.py and benchmark/moe_grouped_gemm/).
 """
 from .quantize import quantize_weights, dequantize_weights, reference_quantized_linear
 from .module import QuantizedLinear
-from .moe import MoEINT4, quantize_weights_moe, QuantizedMoE, QuantizedMoEExpert
+from .moe import MoEINT4, quantize_weights_moe, QuantizedMoE, QuantizedMoEExpert, QuantizedMoEFFN
 from .routing import (RoutingResult, simulate_routing, balanced_routing, create_expert_inputs,
                       combine_expert_outputs, dispatch_grouped, dispatch_indices, combine_grouped)
 
 __all__ = [
     "quantize_weights", "dequantize_weights", "reference_quantized_linear", "QuantizedLinear",
-    "MoEINT4", "quantize_weights_moe", "QuantizedMoE", "QuantizedMoEExpert",
+    "MoEINT4", "quantize_weights_moe", "QuantizedMoE", "QuantizedMoEExpert", "QuantizedMoEFFN",
     "RoutingResult", "simulate_routing", "balanced_routing", "create_expert_inputs",
     "combine_expert_outputs", "dispatch_grouped", "dispatch_indices", "combine_grouped",
 ]

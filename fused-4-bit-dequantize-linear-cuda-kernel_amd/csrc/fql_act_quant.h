@@ -74,7 +74,12 @@ __device__ __forceinline__ float act_widen(unsigned short h)
     return __uint_as_float((uint32_t)h << 16);
 }
 
-template <int L, bool VEC, int IN>
+// GATE (float32 input only): the source row is [gate (K) | up (K)] and the value that gets quantised is
+// silu(gate[k]) * up[k] -- the elementwise step between the two GEMMs of a gated FFN expert fused into the
+// second GEMM's pre-pass, so the [T, K] hidden activation is never materialised.
+__device__ __forceinline__ float act_silu_mul(float g, float u) { return (g / (1.0f + expf(-g))) * u; }
+
+template <int L, bool VEC, int IN, bool GATE = false>
 __global__ __launch_bounds__(256) void act_fused_kernel(
     const void *__restrict__ xin, const int32_t *__restrict__ gather, int n_src, float *__restrict__ delta,
     int32_t *__restrict__ rowsum, int8_t *__restrict__ limbs, int T, int K, int KB, int MBT, int rblocks,
@@ -147,8 +152,9 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
     const int r = tid & 7, col = tid >> 3;        // row of the workgroup, chunk column 0..31
     const int tok = s_tok[r];
     const int p = p0 + r, mb = p >> 5, r32 = p & 31;
+    static_assert(!GATE || IN == 0, "the gated pre-pass takes float32 rows");
     const char *xr = reinterpret_cast<const char *>(xin) +
-                     (size_t)(tok >= 0 ? source_row(gather, n_src, tok) : 0) * K * ES;
+                     (size_t)(tok >= 0 ? source_row(gather, n_src, tok) : 0) * K * ES * (GATE ? 2 : 1);
     const int nch = KB * 16;                      // 16-float chunks per padded row
     const int slabs = (nch + 32 * ACT_CH - 1) / (32 * ACT_CH);
 
@@ -163,7 +169,15 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
             const int k0 = (slab * 32 * ACT_CH + col + 32 * j) * 16;
             if (VEC) {
                 const char *src = xr + (size_t)(k0 < K ? k0 : 0) * ES;
-                if (IN == 0) {
+                if (IN == 0 && GATE) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const v4f gq = *reinterpret_cast<const v4f *>(src + 16 * q);
+                        const v4f uq = *reinterpret_cast<const v4f *>(src + (size_t)K * 4 + 16 * q);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) xv[j][q][i] = act_silu_mul(gq[i], uq[i]);
+                    }
+                } else if (IN == 0) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) xv[j][q] = *reinterpret_cast<const v4f *>(src + 16 * q);
                 } else {                          // 16 halves = two 16-byte loads
@@ -185,7 +199,8 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
                         const int k = k0 + 4 * q + i;
                         float v = 0.0f;
                         if (k < K) {
-                            if (IN == 0) v = reinterpret_cast<const float *>(xr)[k];
+                            if (IN == 0 && GATE) v = act_silu_mul(reinterpret_cast<const float *>(xr)[k], reinterpret_cast<const float *>(xr)[K + k]);
+                            else if (IN == 0) v = reinterpret_cast<const float *>(xr)[k];
                             else v = act_widen<IN>(reinterpret_cast<const unsigned short *>(xr)[k]);
                         }
                         xv[j][q][i] = v;

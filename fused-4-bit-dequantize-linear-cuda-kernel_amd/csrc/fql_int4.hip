@@ -114,7 +114,7 @@ inline int dtype_bytes(int dt) { return dt == FQL_DTYPE_F32 ? 4 : 2; }
 template <int L>
 int launch_act_quant(const void *x, int in_dtype, const int32_t *gather, int n_src, const Workspace &w, int T, int K,
                      int Kp, int MBT, void *out, int out_dtype, int N, const int32_t *tpe, const int32_t *offs, int E,
-                     hipStream_t st)
+                     hipStream_t st, bool gated = false)
 {
     // 8-row workgroups over the padded rows that can hold real rows (every expert's rows rounded up to 32), plus
     // (MoE entry point) the workgroups that zero the rows of `out` no expert covers
@@ -124,7 +124,8 @@ int launch_act_quant(const void *x, int in_dtype, const int32_t *gather, int n_s
     const bool vec = (K % 16 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
     void (*kern)(const void *, const int32_t *, int, float *, int32_t *, int8_t *, int, int, int, int, int, void *, int,
                  int, const int32_t *, const int32_t *, int);
-    switch (in_dtype) {
+    if (gated) kern = vec ? act_fused_kernel<L, true, 0, true> : act_fused_kernel<L, false, 0, true>;
+    else switch (in_dtype) {
     case FQL_DTYPE_F16: kern = vec ? act_fused_kernel<L, true, 1> : act_fused_kernel<L, false, 1>; break;
     case FQL_DTYPE_BF16: kern = vec ? act_fused_kernel<L, true, 2> : act_fused_kernel<L, false, 2>; break;
     default: kern = vec ? act_fused_kernel<L, true, 0> : act_fused_kernel<L, false, 0>; break;
@@ -247,7 +248,7 @@ inline int choose_cfg(int L, int E, int T, int K, int N, bool grouped)
 
 int run_mfma(int L, const void *x, int in_dtype, const int32_t *gather, int n_src, const uint8_t *packed,
              const float *scales, const float *zps, void *out, int out_dtype, const int32_t *tpe, const int32_t *offs,
-             int E, int T, int K, int N, void *workspace, size_t workspace_bytes, hipStream_t st)
+             int E, int T, int K, int N, void *workspace, size_t workspace_bytes, hipStream_t st, bool gated = false)
 {
     const int Kp = padded_k(K);
     const int MBT = row_blocks(T, E);
@@ -258,16 +259,16 @@ int run_mfma(int L, const void *x, int in_dtype, const int32_t *gather, int n_sr
     const int cfg = choose_cfg(L, E, T, K, N, tpe != nullptr);
     int rc;
     if (L == 1) {
-        rc = launch_act_quant<1>(x, in_dtype, gather, n_src, w, T, K, Kp, MBT, zero_out, out_dtype, N, tpe, offs, E, st);
+        rc = launch_act_quant<1>(x, in_dtype, gather, n_src, w, T, K, Kp, MBT, zero_out, out_dtype, N, tpe, offs, E, st, gated);
         if (rc != FQL_OK) return rc;
         return launch_gemm<1>(cfg, w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, st);
     }
     if (L == 2) {
-        rc = launch_act_quant<2>(x, in_dtype, gather, n_src, w, T, K, Kp, MBT, zero_out, out_dtype, N, tpe, offs, E, st);
+        rc = launch_act_quant<2>(x, in_dtype, gather, n_src, w, T, K, Kp, MBT, zero_out, out_dtype, N, tpe, offs, E, st, gated);
         if (rc != FQL_OK) return rc;
         return launch_gemm<2>(cfg, w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, st);
     }
-    rc = launch_act_quant<3>(x, in_dtype, gather, n_src, w, T, K, Kp, MBT, zero_out, out_dtype, N, tpe, offs, E, st);
+    rc = launch_act_quant<3>(x, in_dtype, gather, n_src, w, T, K, Kp, MBT, zero_out, out_dtype, N, tpe, offs, E, st, gated);
     if (rc != FQL_OK) return rc;
     return launch_gemm<3>(cfg, w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, st);
 }
@@ -465,6 +466,24 @@ int fql_moe_fwd(const uint8_t *packed, const float *scales, const float *zps, co
     if (!mfma_eligible(L, T, E, K, N, packed)) return FQL_ERR_DTYPE;
     return run_mfma(L, inputs, in_dtype, nullptr, 0, packed, scales, zps, out, out_dtype, tokens_per_expert,
                     input_offsets, E, T, K, N, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int fql_moe_gated_fwd_f32(const uint8_t *packed, const float *scales, const float *zps, const float *gate_up,
+                          const int32_t *tokens_per_expert, const int32_t *input_offsets, float *out, int E, int T,
+                          int K, int N, int precision, void *workspace, size_t workspace_bytes, void *stream)
+{
+    const int L = limbs_of(precision);
+    if (L < 0) return FQL_ERR_BAD_PRECISION;
+    if (E <= 0 || T < 0 || K <= 0 || N < 0) return FQL_ERR_BAD_SHAPE;
+    if (K & 1) return FQL_ERR_ODD_K;
+    if (T == 0 || N == 0) return FQL_OK;
+    if (!packed || !scales || !zps || !gate_up || !out) return FQL_ERR_NULL_POINTER;
+    if ((tokens_per_expert == nullptr) != (input_offsets == nullptr)) return FQL_ERR_NULL_POINTER;
+    if (tokens_per_expert == nullptr && E != 1) return FQL_ERR_BAD_SHAPE;
+    if (E > 65535) return FQL_ERR_BAD_SHAPE;
+    if (!mfma_eligible(L, T, E, K, N, packed)) return FQL_ERR_ALIGNMENT;   // the fused activation exists on the MFMA path only
+    return run_mfma(L, gate_up, FQL_DTYPE_F32, nullptr, 0, packed, scales, zps, out, FQL_DTYPE_F32, tokens_per_expert,
+                    input_offsets, E, T, K, N, workspace, workspace_bytes, static_cast<hipStream_t>(stream), true);
 }
 
 int fql_route_plan_i32(const int32_t *expert_of_slot, int n_slots, int top_k, int E, int32_t *counts,

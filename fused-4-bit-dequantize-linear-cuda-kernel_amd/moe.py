@@ -181,3 +181,60 @@ class QuantizedMoE(nn.Module):
     @property
     def total_memory_bytes(self) -> int:
         return sum(e.weight_memory_bytes for e in self.experts)
+
+
+class QuantizedMoEFFN(nn.Module):
+    """Full gated FFN experts in INT4: ``down( silu(gate(x)) * up(x) )`` per expert, rows
+    pre-grouped by expert.  The reference models only the up projection ("just the up projection for
+    simplicity", benchmark/moe_grouped_gemm/config.py:50-52); this is the step either side of it in a
+    Mixtral / DeepSeek block, built from the same kernels:
+
+      * gate and up are ONE grouped GEMM over the stacked ``[E, 2F, H]`` weights (one pass over x),
+      * silu(gate) * up is fused into the down GEMM's activation pre-pass (``fql_moe_gated_fwd_f32``),
+        so the ``[T, F]`` hidden activation never exists in memory.
+
+    Weights are quantised per output row with ``quantize_weights`` (per-row scale / zero point, as
+    ``QuantizedMoEExpert.from_fp16`` does)."""
+
+    def __init__(self, num_experts: int, hidden_dim: int, ffn_dim: int, precision: str = "default"):
+        super().__init__()
+        assert hidden_dim % 32 == 0 and ffn_dim % 32 == 0, "hidden_dim and ffn_dim must be multiples of 32"
+        self.num_experts, self.hidden_dim, self.ffn_dim, self.precision = num_experts, hidden_dim, ffn_dim, precision
+        E, H, F = num_experts, hidden_dim, ffn_dim
+        self.register_buffer("gate_up_packed", torch.zeros(E, 2 * F, H // 2, dtype=torch.uint8))
+        self.register_buffer("gate_up_scales", torch.zeros(E, 2 * F, dtype=torch.float32))
+        self.register_buffer("gate_up_zero_points", torch.zeros(E, 2 * F, dtype=torch.float32))
+        self.register_buffer("down_packed", torch.zeros(E, H, F // 2, dtype=torch.uint8))
+        self.register_buffer("down_scales", torch.zeros(E, H, dtype=torch.float32))
+        self.register_buffer("down_zero_points", torch.zeros(E, H, dtype=torch.float32))
+
+    @classmethod
+    def from_weights(cls, gate: List[torch.Tensor], up: List[torch.Tensor], down: List[torch.Tensor],
+                     precision: str = "default") -> "QuantizedMoEFFN":
+        """``gate[e]``, ``up[e]``: ``[F, H]``; ``down[e]``: ``[H, F]`` (nn.Linear weight layout)."""
+        E = len(gate)
+        F, H = gate[0].shape
+        m = cls(E, H, F, precision)
+        gu = [quantize_weights(torch.cat([g.float(), u.float()], dim=0)) for g, u in zip(gate, up)]
+        dn = [quantize_weights(d.float()) for d in down]
+        m.gate_up_packed = torch.stack([t[0] for t in gu])
+        m.gate_up_scales = torch.stack([t[1] for t in gu])
+        m.gate_up_zero_points = torch.stack([t[2] for t in gu])
+        m.down_packed = torch.stack([t[0] for t in dn])
+        m.down_scales = torch.stack([t[1] for t in dn])
+        m.down_zero_points = torch.stack([t[2] for t in dn])
+        return m
+
+    def forward(self, inputs, tokens_per_expert, input_offsets):
+        """inputs ``[T, H]`` float32 rows grouped by expert -> ``[T, H]`` float32."""
+        if not inputs.is_cuda:
+            raise RuntimeError("QuantizedMoEFFN runs on the GPU (the product path has no CPU fallback)")
+        from . import ops
+        gate_up = ops.moe_forward(self.gate_up_packed, self.gate_up_scales, self.gate_up_zero_points, inputs, None,
+                                  tokens_per_expert, input_offsets, precision=self.precision)
+        return ops.moe_gated_forward(self.down_packed, self.down_scales, self.down_zero_points, gate_up,
+                                     tokens_per_expert, input_offsets, precision=self.precision)
+
+    @property
+    def total_memory_bytes(self) -> int:
+        return sum(b.numel() * b.element_size() for b in self.buffers())

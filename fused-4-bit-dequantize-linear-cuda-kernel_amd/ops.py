@@ -254,6 +254,35 @@ def moe_gather_forward(packed_weights, scales, zero_points, tokens, row_index, t
     return out
 
 
+def moe_gated_forward(packed_weights, scales, zero_points, gate_up, tokens_per_expert, input_offsets,
+                      precision="default"):
+    """Second GEMM of a gated FFN expert with the activation fused into its pre-pass:
+    ``out[t] = W_e @ (silu(gate_up[t, :K]) * gate_up[t, K:])``; ``gate_up`` [T, 2K] float32 (the output of the
+    fused gate|up projection), ``packed_weights`` [E, N, K/2].  The [T, K] hidden activation is never written."""
+    if not gate_up.is_cuda or gate_up.dtype != torch.float32 or gate_up.dim() != 2:
+        raise RuntimeError("gate_up must be a CUDA float32 [T, 2K] tensor")
+    E, N, packed_dim = packed_weights.shape
+    T, K2 = gate_up.shape
+    K = K2 // 2
+    if K2 % 2 or packed_dim * 2 != K or K % 32:
+        raise RuntimeError("gate_up must be [T, 2K] with K = 2 * packed_weights.shape[2] and K % 32 == 0")
+    dev = gate_up.device
+    gate_up = gate_up.contiguous()
+    tpe = tokens_per_expert.to(device=dev, dtype=torch.int32).contiguous()
+    offs = input_offsets.to(device=dev, dtype=torch.int32).contiguous()
+    L = _native.lib()
+    prec = _precision(precision)
+    out = torch.empty((T, N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        ws, ws_ptr = _workspace(L.fql_moe_workspace_bytes(E, T, K, N, prec), dev)
+        rc = L.fql_moe_gated_fwd_f32(packed_weights.contiguous().data_ptr(), scales.contiguous().data_ptr(),
+                                     zero_points.contiguous().data_ptr(), gate_up.data_ptr(), tpe.data_ptr(),
+                                     offs.data_ptr(), out.data_ptr(), E, T, K, N, prec,
+                                     ws_ptr, 0 if ws is None else ws.numel(), _stream_ptr(dev))
+    _native.check(rc, "fql_moe_gated_fwd_f32")
+    return out
+
+
 ROUTE_MAX_EXPERTS = 128
 
 

@@ -212,6 +212,20 @@ FQL_API int fql_moe_fwd(const uint8_t *packed, const float *scales, const float 
                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Second GEMM of a gated FFN expert with the activation fused in (the reference models
+ * only the up projection, benchmark/moe_grouped_gemm/config.py:50-52):
+ *   out[t][:] = W_e * ( silu(gate_up[t][0:K]) (.) gate_up[t][K:2K] )
+ * gate_up is the [T, 2K] float32 output of the fused gate|up projection (one grouped GEMM over the stacked
+ * [E, 2K, H] weights); the [T, K] hidden activation is never written.  tokens_per_expert / input_offsets as in
+ * fql_moe_fwd_f32, or both NULL with E = 1 for a dense layer.  MFMA path only (K % 32 == 0, 16-byte aligned
+ * packed weights): FQL_ERR_ALIGNMENT otherwise.  Workspace: fql_moe_workspace_bytes(E, T, K, N, precision).
+ * ------------------------------------------------------------------------------------- */
+FQL_API int fql_moe_gated_fwd_f32(const uint8_t *packed, const float *scales, const float *zps,
+                                  const float *gate_up, const int32_t *tokens_per_expert,
+                                  const int32_t *input_offsets, float *out, int E, int T, int K, int N,
+                                  int precision, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Routing either side of the grouped GEMM, one launch each (reference: the torch index ops of
  * benchmark/moe_grouped_gemm/routing.py:117-149 create_expert_inputs and :172-189 combine_expert_outputs).
  *

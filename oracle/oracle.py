@@ -210,3 +210,27 @@ def reference_roofline_model(K: int, N: int):
     bytes_read = K * 4 + N * (K // 2) + N * 4 + N * 4
     flops = 2 * K * N
     return bytes_read, flops
+
+
+def gated_ffn_grouped(gate_up_q, down_q, x, counts, offsets):
+    """CPU restatement of a gated FFN expert over rows grouped by expert (no reference
+    counterpart: the reference models the up projection only, benchmark/moe_grouped_gemm/config.py:50-52):
+    ``out = Wd_e @ (silu(Wg_e @ x) * (Wu_e @ x))`` with the de-quantised weights, float64 accumulation.
+    ``gate_up_q`` / ``down_q``: (packed [E, rows, cols/2], scales [E, rows], zero_points [E, rows])."""
+    Pg, Sg, Zg = gate_up_q
+    Pd, Sd, Zd = down_q
+    E, F2, _ = Pg.shape
+    F = F2 // 2
+    H = Pd.shape[1]
+    out = np.zeros((x.shape[0], H), dtype=np.float64)
+    for e in range(E):
+        c, o = int(counts[e]), int(offsets[e])
+        if c == 0:
+            continue
+        wgu = dequantize_weights(Pg[e], Sg[e], Zg[e]).astype(np.float64)
+        wd = dequantize_weights(Pd[e], Sd[e], Zd[e]).astype(np.float64)
+        gu = x[o:o + c].astype(np.float64) @ wgu.T
+        g, u = gu[:, :F], gu[:, F:]
+        h = (g / (1.0 + np.exp(-g))) * u
+        out[o:o + c] = h @ wd.T
+    return out
