@@ -1,0 +1,345 @@
+// Grouped INT4 x INT8-limb GEMM for DECODE-SIZE row groups (<= 16 rows per expert per tile): the op is a weight
+// stream (4.5 flop per weight byte per row), so the kernel is organised around one rule learnt from the phase
+// traces of the 32-row kernel: vector-memory loads of a wave complete IN ORDER, so a
+// short-lead load issued after a long-lead (HBM) load waits for the whole HBM round trip.  Here EVERY load of a
+// wave has the same lead of one full 256-k stage and is issued at a stage boundary:
+//   * weights of the next stage(s): 8 rows x 128 B full lines -> VGPR ring (BD stages) -> wave-private LDS slab,
+//   * ALL activation fragments of the next stage: v_mfma_i32_16x16x64_i8 needs only 16 rows, so a whole stage of
+//     activations is 4 steps x L limbs x 4 registers (48 at 3 limbs) -- it fits in registers twice (current +
+//     next), which the 32x32x32 shape could not afford,
+//   * the tile's scale / zero-point slice and per-row values with its first stage (scales through LDS),
+//   * the next tile's first stages while the current tile finishes (rings run across tile boundaries).
+// Inside a stage a wave issues only LDS reads, unpacks and MFMAs.  No barrier in the K loop: the 8 waves of a
+// workgroup split K KG ways and the columns 8/KG ways and own their weight rows privately; the KG partial sums
+// are added pairwise through LDS at the end (int32: exact).  Bit-identical to every other tile configuration.
+//
+// Activation fragments come from the same fragment-native limb workspace as the 32-row kernels: the 16-byte
+// piece (k-step ks, lane group g, row r) of a 256-k block holds k = 64 v + 32 g + 16 b (+0..15) with ks = 2v + b;
+// the 64-k MFMA step s takes k-slice kq = lane >> 4 from piece (ks = 2s + (kq & 1), g = kq >> 1), and the weight
+// operand takes the same slice from bytes [8 (kq & 1), +8) of 16-byte chunk 2s + (kq >> 1) of its row's segment.
+#pragma once
+#include "fql_common.h"
+#include "fql_gemm_i8.h"
+
+template <int L, int NF, int KG, int BDEPTH>
+struct Rows16Cfg {
+    static constexpr int NW = 8;
+    static constexpr int NG = NW / KG;
+    static constexpr int THREADS = 64 * NW;
+    static constexpr int BM = 16;
+    static constexpr int BN = 16 * NF * NG;
+    static constexpr int BD = BDEPTH;
+    static constexpr int UNR = (BDEPTH % 2 == 0) ? BDEPTH : 2 * BDEPTH;   // stages per unrolled trip: ring slot and
+                                                                          // activation parity are compile-time
+    static constexpr int PIECES = NF * 2;                     // 1 KiB weight pieces (8 rows x 128 B) per wave per stage
+    static constexpr int SLAB = NF * 16 * (FQL_KB / 2);       // wave-private LDS bytes: one stage of packed weights
+    static constexpr int ACC_BYTES = L * NF * 4 * 64 * 4;
+    static constexpr int RED_BYTES = (KG > 1) ? (KG / 2) * NG * ACC_BYTES : 0;
+    static constexpr int MAIN_BYTES = (NW * SLAB > RED_BYTES) ? NW * SLAB : RED_BYTES;
+    static constexpr int SZ_BYTES = 2 * 2 * BN * 4;           // scale / zero-point slices of two tiles
+    static constexpr int LDS_BYTES = MAIN_BYTES + SZ_BYTES;
+    static constexpr int SZN = (2 * BN + THREADS - 1) / THREADS;
+    static_assert(KG == 1 || KG == 2 || KG == 4 || KG == 8, "K split");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <int L, int NF, int KG, int BDEPTH>
+__global__ __launch_bounds__(512, 2) void gemm_i8_rows16_kernel(
+    const int8_t *__restrict__ limbs, const float *__restrict__ delta,
+    const int32_t *__restrict__ rowsum, const uint8_t *__restrict__ packed,
+    const float *__restrict__ scales, const float *__restrict__ zps, void *__restrict__ out, int out_kind,
+    const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
+    int E, int T, int K, int Kp, int MBT, int N, int n_tiles, int m_slots)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    using C = Rows16Cfg<L, NF, KG, BDEPTH>;
+    constexpr int NG = C::NG, BD = C::BD;
+    constexpr int OOB = 0x7fff0000;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave / NG, ng = wave - kg * NG;
+    const int l15 = lane & 15, kq = lane >> 4;
+
+    // ---- expert table: ONE pass over the device-side counts per workgroup, kept in LDS (first 64 experts; more
+    //      experts fall back to re-reading per tile), so finding a tile's expert later costs no global load and no
+    //      wait behind the weight stream
+    __shared__ int s_lo[64], s_cnt[64], s_tex[64], s_pex[64];
+    int n_real = m_slots * n_tiles;
+    if (tpe != nullptr) {
+        int cp = 0, ct = 0;
+        for (int base = 0; base < E; base += 64) {
+            const ExpertLane x = expert_chunk(tpe, offs, E, T, C::BM, base, lane, cp, ct);
+            if (base == 0 && wave == 0) { s_lo[lane] = x.lo; s_cnt[lane] = x.cnt; s_tex[lane] = x.tile_excl; s_pex[lane] = x.pad_excl; }
+        }
+        const int m_tiles = ct < m_slots ? ct : m_slots;
+        n_real = m_tiles * n_tiles;
+    }
+    n_real = __builtin_amdgcn_readfirstlane(n_real);
+    __syncthreads();
+
+    auto tile_params = [&](int vb) -> GemmTile {
+        GemmTile tp = {0, 0, 0, 0, 0, 0};
+        if (vb >= n_real) return tp;
+        const int tile = xcd_remap(vb, n_real);
+        const int ms = tile / n_tiles;
+        tp.nt = tile - ms * n_tiles;
+        if (tpe == nullptr) {
+            tp.row0 = tp.prow0 = ms * C::BM;
+            tp.rows_valid = T - tp.row0;
+            tp.ok = 1;
+        } else {
+            // first 64 experts from LDS (lane i looks at expert i)
+            {
+                const int lo = s_lo[lane], cnt = s_cnt[lane], te = s_tex[lane], pe = s_pex[lane];
+                const int tiles_e = (cnt + C::BM - 1) / C::BM;
+                const unsigned long long hit = __ballot(lane < E && ms >= te && ms < te + tiles_e);
+                if (hit) {
+                    const int src = __ffsll((long long)hit) - 1;
+                    const int lo_s = __shfl(lo, src, 64), cnt_s = __shfl(cnt, src, 64);
+                    const int te_s = __shfl(te, src, 64), pe_s = __shfl(pe, src, 64);
+                    tp.e = src;
+                    tp.row0 = lo_s + (ms - te_s) * C::BM;
+                    tp.prow0 = pe_s + (ms - te_s) * C::BM;    // experts are padded to 32 rows: a 16-row tile is one half block
+                    tp.rows_valid = cnt_s - (ms - te_s) * C::BM;
+                    tp.ok = 1;
+                }
+            }
+            if (!tp.ok && E > 64) {
+                int cp = 0, ct = 0;
+                for (int base = 0; base < E && !tp.ok; base += 64) {
+                    const ExpertLane x = expert_chunk(tpe, offs, E, T, C::BM, base, lane, cp, ct);
+                    const unsigned long long hit = __ballot(ms >= x.tile_excl && ms < x.tile_excl + x.tiles);
+                    if (hit && base > 0) {
+                        const int src = __ffsll((long long)hit) - 1;
+                        const int lo = __shfl(x.lo, src, 64), cnt = __shfl(x.cnt, src, 64);
+                        const int te = __shfl(x.tile_excl, src, 64), pe = __shfl(x.pad_excl, src, 64);
+                        tp.e = base + src;
+                        tp.row0 = lo + (ms - te) * C::BM;
+                        tp.prow0 = pe + (ms - te) * C::BM;
+                        tp.rows_valid = cnt - (ms - te) * C::BM;
+                        tp.ok = 1;
+                    }
+                }
+            }
+        }
+        if (tp.rows_valid <= 0) tp.ok = 0;
+        if (tp.rows_valid > C::BM) tp.rows_valid = C::BM;
+        tp.e = __builtin_amdgcn_readfirstlane(tp.e);
+        tp.row0 = __builtin_amdgcn_readfirstlane(tp.row0);
+        tp.prow0 = __builtin_amdgcn_readfirstlane(tp.prow0);
+        tp.rows_valid = __builtin_amdgcn_readfirstlane(tp.rows_valid);
+        tp.nt = __builtin_amdgcn_readfirstlane(tp.nt);
+        tp.ok = __builtin_amdgcn_readfirstlane(tp.ok);
+        return tp;
+    };
+
+    const int KB = Kp / FQL_KB, KT = KB;
+    const int SP = ((KT + KG - 1) / KG + C::UNR - 1) / C::UNR * C::UNR;   // stages per wave per tile, padded (even)
+    const size_t wbytes = (size_t)N * (size_t)(K >> 1);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)limbs, 0, (int)((size_t)L * KB * MBT * 8192), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)delta, 0, T * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)rowsum, 0, L * T * 4, 0x00020000);
+    const int a_stage = MBT * 8192;
+    const int a_limb = KB * MBT * 8192;
+
+    // ---- tile-independent per-lane offsets
+    const int aoff0 = ((kq & 1) * 64 + (kq >> 1) * 32 + l15) * 16;   // piece (ks = 2s + (kq&1), g = kq>>1, row) of a block
+    char *slab = lds + wave * C::SLAB;
+    const int rowW = lane >> 3, chW = lane & 7;                // piece i: rows 8i + rowW
+    const int vrel0 = rowW * (K >> 1) + chW * 16;
+    // LDS image: row * 128 + 16 * (chunk ^ ((row >> 1) & 7)); row = 8 i + rowW, so the swizzle term alternates
+    // with the parity of the piece
+    const int wB0 = rowW * 128 + 16 * (chW ^ ((rowW >> 1) & 7));            // even pieces (+ i * 1024)
+    const int wB1 = rowW * 128 + 16 * (chW ^ (((rowW >> 1) + 4) & 7));      // odd pieces
+    const int rB0 = l15 * 128 + 8 * (kq & 1);                  // fragment j: + j * 2048; chunk 2s + (kq>>1), swizzled
+    const int swB0 = (l15 >> 1) & 7;
+    float *szbuf = reinterpret_cast<float *>(lds + C::MAIN_BYTES);
+
+    auto w_rsrc = [&](const GemmTile &tp) {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(packed + (size_t)tp.e * wbytes), 0, (int)wbytes, 0x00020000);
+    };
+    auto w_soff = [&](const GemmTile &tp, int s) -> int {      // stage s of this K group in tile tp, or out of bounds
+        const int kt = kg + s * KG;
+        return (tp.ok && kt < KT) ? (tp.nt * C::BN + ng * NF * 16) * (K >> 1) + kt * (FQL_KB / 2) : OOB;
+    };
+    auto a_soff = [&](const GemmTile &tp, int s) -> int {
+        const int kt = kg + s * KG;
+        return (tp.ok && kt < KT) ? (tp.prow0 >> 5) * 8192 + ((tp.prow0 >> 4) & 1) * 256 + kt * a_stage : 0;
+    };
+
+    // ---- rings: BD weight stages + ONE full activation stage ahead, running across tile boundaries
+    v4i bst[BD][C::PIECES];
+    v4i afr[2][4][L];                                          // [parity of the stage][64-k step][limb]
+    float szr[C::SZN];
+    int drow[1 + L];                                           // delta bits and limb row sums of this lane's row
+    auto issue_weights = [&](const __amdgpu_buffer_rsrc_t rs, int so, int slot) {
+#pragma unroll
+        for (int i = 0; i < C::PIECES; ++i)
+            bst[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vrel0, so + i * 8 * (K >> 1), 0);
+    };
+    auto issue_acts = [&](int so, int par) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+                afr[par][s][l] = __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff0, so + l * a_limb + s * 2048, 0);
+    };
+    auto issue_tile_consts = [&](const GemmTile &tp) {         // scale / zero-point slice and this lane's row values
+        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(scales + (size_t)tp.e * N), 0, N * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(zps + (size_t)tp.e * N), 0, N * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < C::SZN; ++i) {
+            const int idx = tid + i * C::THREADS;
+            const bool is_s = idx < C::BN;
+            const int col = is_s ? idx : idx - C::BN;
+            const int so = (tp.ok && idx < 2 * C::BN) ? 0 : OOB;
+            const int vo = (tp.nt * C::BN + col) * 4;
+            const int vs = __builtin_amdgcn_raw_buffer_load_b32(rsS, is_s ? vo : OOB, so, 0);
+            const int vz = __builtin_amdgcn_raw_buffer_load_b32(rsZ, is_s ? OOB : vo, so, 0);
+            szr[i] = __builtin_bit_cast(float, vs | vz);
+        }
+        const int t = (tp.ok && l15 < tp.rows_valid) ? tp.row0 + l15 : 0;
+        drow[0] = __builtin_amdgcn_raw_buffer_load_b32(rsD, t * 4, 0, 0);
+#pragma unroll
+        for (int l = 0; l < L; ++l) drow[1 + l] = __builtin_amdgcn_raw_buffer_load_b32(rsR, (l * T + t) * 4, 0, 0);
+    };
+
+    int ev = 0;
+    FQL_STAMP(ev++);                                           // kernel entry
+    GemmTile cur = tile_params(blockIdx.x);
+    {
+        const __amdgpu_buffer_rsrc_t rs = w_rsrc(cur);
+        issue_acts(a_soff(cur, 0), 0);
+        issue_tile_consts(cur);
+#pragma unroll
+        for (int u = 0; u < BD; ++u) issue_weights(rs, w_soff(cur, u), u);
+    }
+    int parity = 0;                                            // tile parity (scale slice buffer)
+
+  for (int vb = blockIdx.x; vb < n_real; vb += gridDim.x, parity ^= 1) {
+    FQL_STAMP(ev++);                                           // tile start
+    const GemmTile nxt = tile_params(vb + gridDim.x);
+    FQL_STAMP(ev++);                                           // next tile known
+    const __amdgpu_buffer_rsrc_t rs_cur = w_rsrc(cur), rs_nxt = w_rsrc(nxt);
+    float *sz = szbuf + parity * 2 * C::BN;
+    // this tile's constants arrived with its first stage: park the scale slice, keep the row values
+#pragma unroll
+    for (int i = 0; i < C::SZN; ++i)
+        if (tid + i * C::THREADS < 2 * C::BN) sz[tid + i * C::THREADS] = szr[i];
+    const float d = __builtin_bit_cast(float, drow[0]);
+    float rsum[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) rsum[l] = (float)drow[1 + l];
+
+    v4i acc[L][NF];
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[l][j] = v4i{0, 0, 0, 0};
+
+    for (int s0 = 0; s0 < SP; s0 += C::UNR) {
+#pragma unroll
+      for (int uu = 0; uu < C::UNR; ++uu) {
+        const int s = s0 + uu;
+        constexpr int dummy = 0; (void)dummy;
+        const int u = uu % BD;                                 // weight ring slot (static after unrolling)
+        const int apar = uu & 1;                               // activation stage parity (SP is even: static)
+        FQL_STAMP(ev++);                                       // stage start
+        // ---- stage boundary: park this stage's weights, then issue EVERYTHING the next stage(s) need
+#pragma unroll
+        for (int i = 0; i < C::PIECES; ++i) *reinterpret_cast<v4i *>(slab + ((i & 1) ? wB1 : wB0) + i * 1024) = bst[u][i];
+        {   // order matters (loads complete in order): the L2-resident activations of the NEXT stage first, the HBM
+            // weights of the stage BD ahead last, so the next boundary's wait for the activations does not include
+            // the youngest HBM loads
+            const bool ahere = s + 1 < SP;
+            issue_acts(ahere ? a_soff(cur, s + 1) : a_soff(nxt, 0), apar ^ 1);
+            if (s + 1 == SP) issue_tile_consts(nxt);          // with the next tile's first activation stage
+            const bool here = s + BD < SP;
+            issue_weights(here ? rs_cur : rs_nxt, here ? w_soff(cur, s + BD) : w_soff(nxt, s + BD - SP), u);
+        }
+        // ---- 4 MFMA steps of 64 k: LDS reads, unpack, matrix cores; no memory instruction in here
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            v4i wfr[NF];
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const uint2 raw = *reinterpret_cast<const uint2 *>(slab + rB0 + j * 2048 + 16 * ((2 * st + (kq >> 1)) ^ swB0));
+                uint32_t lo0, hi0, lo1, hi1;
+                unpack8(raw.x, lo0, hi0);
+                unpack8(raw.y, lo1, hi1);
+                wfr[j] = v4i{(int)lo0, (int)hi0, (int)lo1, (int)hi1};
+            }
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    acc[l][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wfr[j], afr[apar][st][l], acc[l][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    FQL_STAMP(ev++);                                           // K loop done
+    // ---- add the KG partial accumulators through LDS, pairwise (int32: exact, order-free)
+    if (KG > 1) {
+#pragma unroll
+        for (int sft = 1; sft < KG; sft <<= 1) {
+            char *red = lds + ((kg / (2 * sft)) * NG + ng) * C::ACC_BYTES;
+            __syncthreads();
+            if ((kg & (2 * sft - 1)) == sft) {
+#pragma unroll
+                for (int l = 0; l < L; ++l)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+                        *reinterpret_cast<v4i *>(red + ((l * NF + j) * 64 + lane) * 16) = acc[l][j];
+            }
+            __syncthreads();
+            if ((kg & (2 * sft - 1)) == 0) {
+#pragma unroll
+                for (int l = 0; l < L; ++l)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) {
+                        const v4i p = *reinterpret_cast<const v4i *>(red + ((l * NF + j) * 64 + lane) * 16);
+                        acc[l][j] += p;
+                    }
+            }
+        }
+        __syncthreads();
+    } else {
+        __syncthreads();                                       // the scale slice parked by other waves
+    }
+
+    // ---- epilogue: D = weights x activations, so lane (t = lane & 15, nq = lane >> 4) owns row t and registers
+    //      0..3 are columns 4 nq .. 4 nq + 3 of each 16-column fragment: one 16-byte store per fragment.
+    //      Scales / zero points from LDS, the row values from registers: no global load.
+    FQL_STAMP(ev++);                                           // reduction done
+    const GemmTile done = cur;
+    cur = nxt;
+    if (kg != 0 || !done.ok || l15 >= done.rows_valid) continue;
+    const int t = done.row0 + l15;
+    const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & (out_kind == 0 ? 15 : 7)) == 0);
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int c0 = (ng * NF + j) * 16 + 4 * kq;           // column inside the tile
+        const v4f s4 = *reinterpret_cast<const v4f *>(sz + c0);
+        const v4f z4 = *reinterpret_cast<const v4f *>(sz + C::BN + c0);
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float tot = 0.0f;
+#pragma unroll
+            for (int l = L - 1; l >= 0; --l)
+                tot = fmaf(tot, 256.0f, fmaf(-z4[c], rsum[l], (float)acc[l][j][c]));
+            o[c] = (tot * d) * s4[c];
+        }
+        store_out4(out, out_kind, (size_t)t * N, done.nt * C::BN + c0, N, vec, o);
+    }
+  }
+#endif
+}

@@ -7,6 +7,7 @@
 #include "fql_act_quant.h"
 #include "fql_gemm_i8.h"
 #include "fql_gemm_rows32.h"
+#include "fql_gemm_rows16.h"
 #include "fql_gemv.h"
 #include "fql_generic.h"
 #include "fql_quantize.h"
@@ -80,7 +81,18 @@ constexpr int FQL_NUM_CFG = 11;
     R(6, 1, 8, 2, 1, 4)        /* 32 x  32, two workgroups per CU */ \
     R(7, 1, 2, 2, 1, 4)        /* 32 x 128, two workgroups per CU */
 constexpr int FQL_NUM_ROWS32 = 8;
-inline bool valid_cfg(int cfg) { return (cfg >= 0 && cfg < FQL_NUM_CFG) || (cfg >= 100 && cfg < 100 + FQL_NUM_ROWS32); }
+// Decode-size row groups (fql_gemm_rows16.h): 16-row tiles on v_mfma_i32_16x16x64_i8, every load one stage ahead.
+// ids 200 + i.  S(i, NF, KG, weight stages in flight)
+#define FQL_ROWS16_LIST(S)                                                                                         \
+    S(0, 4, 4, 2)              /* 16 x 128 */ \
+    S(1, 4, 2, 2)              /* 16 x 256 */ \
+    S(2, 4, 4, 1)              /* 16 x 128, one weight stage in flight */ \
+    S(3, 4, 8, 1)              /* 16 x  64 */ \
+    S(4, 8, 4, 1)              /* 16 x 256, 8 fragments per wave */
+constexpr int FQL_NUM_ROWS16 = 5;
+inline bool valid_cfg(int cfg) { return (cfg >= 0 && cfg < FQL_NUM_CFG) || (cfg >= 100 && cfg < 100 + FQL_NUM_ROWS32) ||
+           (cfg >= 200 && cfg < 200 + FQL_NUM_ROWS16);
+}
 
 // The MFMA path addresses its operands through 32-bit buffer offsets.
 inline bool mfma_addressable(int L, int T, int E, int K, int N)
@@ -186,6 +198,31 @@ int launch_rows32_cfg(const Workspace &w, const uint8_t *packed, const float *sc
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
+template <int L, int NF, int KG, int BDEPTH>
+int launch_rows16_cfg(const Workspace &w, const uint8_t *packed, const float *scales, const float *zps, void *out,
+                      int out_dtype, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT,
+                      int N, hipStream_t st)
+{
+    using C = Rows16Cfg<L, NF, KG, BDEPTH>;
+    auto kern = gemm_i8_rows16_kernel<L, NF, KG, BDEPTH>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                C::LDS_BYTES) != hipSuccess)
+            return FQL_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int n_tiles = (N + C::BN - 1) / C::BN;
+    const int m_slots = (tpe == nullptr) ? (T + C::BM - 1) / C::BM : T / C::BM + E;
+    long long blocks = (long long)n_tiles * m_slots;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return FQL_ERR_BAD_SHAPE;
+    const int cus = compute_units();
+    if (blocks > cus) blocks = cus;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, w.limbs, w.delta, w.rowsum,
+                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots);
+    return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
+}
+
 template <int L>
 int launch_gemm(int cfg, const Workspace &w, const uint8_t *packed, const float *scales, const float *zps,
                 void *out, int out_dtype, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT,
@@ -204,6 +241,12 @@ int launch_gemm(int cfg, const Workspace &w, const uint8_t *packed, const float 
                                                         Kp, MBT, N, st);
         FQL_ROWS32_LIST(R)
 #undef R
+#define S(i, nf, kg, bd)                                                                                           \
+    case 200 + i:                                                                                                 \
+        return launch_rows16_cfg<L, nf, kg, bd>(w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, \
+                                                st);
+        FQL_ROWS16_LIST(S)
+#undef S
     default: return FQL_ERR_BAD_SHAPE;
     }
 }
@@ -222,10 +265,12 @@ inline int choose_cfg(int L, int E, int T, int K, int N, bool grouped)
     // weights (N / 64 tiles per row block instead of N / 256)
     const long long wide_tiles = (long long)groups * ((m + 127) / 128) * ((N + 255) / 256);
     if (wide_tiles < 128 && m <= 128) {
+        if (m <= 16) return 203;                             //  16 x 64 decode tiles, K split 8 ways (fql_gemm_rows16.h)
         if (m <= 32) return 8;                               //  32 x 64, 2 waves
         if (m <= 64) return 7;                               //  64 x 64, 4 waves
         return 6;                                            // 128 x 64, 4 waves
     }
+    if (m <= 16) return 202;                                 //  16 x 128 decode tiles: every load one stage ahead
     if (m <= 32) return 100;                                 //  32 x 128, K split 4 ways inside the workgroup
     if (m <= 64) return 9;                                   //  64 x 384
     const int mt = groups * ((m + 127) / 128);
@@ -669,6 +714,7 @@ FQL_API int fql_debug_trace(unsigned long long *dst)
 #endif
 FQL_API int fql_tune_num_configs(void) { return FQL_NUM_CFG; }
 FQL_API int fql_tune_num_rows32_configs(void) { return FQL_NUM_ROWS32; }
+FQL_API int fql_tune_num_rows16_configs(void) { return FQL_NUM_ROWS16; }
 
 
 }  // extern "C"

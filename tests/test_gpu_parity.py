@@ -346,7 +346,7 @@ def test_moe_grouped_parity(fq, E, N, K, counts, gap, prec, tol):
 def test_every_tile_configuration_is_bit_identical(fq, prec, tol):
     """The integer dot products are exact, so the tile shape, the K split inside a workgroup and the row
     grouping must not change a single output bit: sweep every compiled configuration (wide tiles 0..,
-    short-row-group tiles 100..) through the tuning entry point on a ragged grouped problem."""
+    short-row-group tiles 100.., decode-size 16-row tiles 200..) through the tuning entry point on a ragged grouped problem."""
     import ctypes
     from fused_int4_amd import ops, _native
     lib = _native.lib()
@@ -361,7 +361,8 @@ def test_every_tile_configuration_is_bit_identical(fq, prec, tol):
     limbs, delta, rowsum = ops.act_quant(dx, precision=prec, tokens_per_expert=dc, input_offsets=do)
     stream = torch.cuda.current_stream().cuda_stream
     outs = {}
-    for cfg in list(range(lib.fql_tune_num_configs())) + list(range(100, 100 + lib.fql_tune_num_rows32_configs())):
+    for cfg in (list(range(lib.fql_tune_num_configs())) + list(range(100, 100 + lib.fql_tune_num_rows32_configs()))
+                + list(range(200, 200 + lib.fql_tune_num_rows16_configs()))):
         out = torch.full((T, N), float("nan"), dtype=torch.float32, device="cuda")
         rc = tune(cfg, limbs.data_ptr(), delta.data_ptr(), rowsum.data_ptr(), dP.data_ptr(), dS.data_ptr(),
                   dZ.data_ptr(), dc.data_ptr(), do.data_ptr(), out.data_ptr(), E, T, K, N,
