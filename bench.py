@@ -43,6 +43,8 @@ def parse():
                     help="distinct weight copies rotated through so that consecutive steps cannot be served "
                          "from the 256 MB Infinity Cache (4 x 180 MB); 1 = warm-cache numbers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-modes", action="store_true",
+                    help="skip the opt-in precision / float16 side measurements (profiling runs: one kernel variant only)")
     ap.add_argument("--experts", type=int, default=8)
     ap.add_argument("--hidden", type=int, default=4096)
     ap.add_argument("--ffn", type=int, default=11008)
@@ -312,7 +314,7 @@ def main():
         extra.update({"gemv_kernel_ms_avg_graph": k_ms, "graph_launches": n})
 
     # ------------------------------------------------------------------ the opt-in reduced-limb modes, for the record
-    if world == 1 and a.workload == "moe" and prec in ("default", "exact"):
+    if world == 1 and a.workload == "moe" and prec in ("default", "exact") and not a.no_side_modes:
         def time_mode(mode):
             def step_mode():
                 P, S, Z = sets[step_i[0] % len(sets)]

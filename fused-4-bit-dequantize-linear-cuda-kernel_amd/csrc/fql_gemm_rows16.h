@@ -182,6 +182,9 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_rows16_kernel(
             bst[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vrel0, so + i * 8 * (K >> 1), 0);
     };
     auto issue_acts = [&](int so, int par) {
+#if defined(FQL_ABLATE) && FQL_ABLATE == 2          // timing experiment only (wrong results): no activation traffic
+        if (so != 0x12345678) return;
+#endif
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
