@@ -125,12 +125,35 @@ def main():
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal mode (FQL_BENCH_BACKEND=gloo): several ranks share the visible card(s) and the collectives go
+    # through host memory over gloo -- exercises this file's multi-rank path on a 1-GPU box; never a measurement.
+    rehearsal = os.environ.get("FQL_BENCH_BACKEND", "nccl") == "gloo"
+    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+            import fused_int4_amd.ep as _ep
+            _real_a2a = dist.all_to_all_single
+
+            def _a2a_through_host(output, input, output_split_sizes=None, input_split_sizes=None, group=None):
+                o = torch.empty(output.shape, dtype=output.dtype)
+                _real_a2a(o, input.cpu().contiguous(), output_split_sizes, input_split_sizes, group=group)
+                output.copy_(o)
+            _ep.dist.all_to_all_single = _a2a_through_host
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    def all_reduce_max(t):
+        if rehearsal:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
 
     import fused_int4_amd as fq
     from fused_int4_amd import ops, routing as R
@@ -193,6 +216,7 @@ def main():
             step_i[0] += 1
             return ep(x, idx, wts)
         phases = None
+        ep_objects = eps
         rows = a.tokens * a.top_k
         flops = 2.0 * rows * K * N
         weight_bytes = E * N * (K // 2)
@@ -235,14 +259,42 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        all_reduce_max(tmax)
         elapsed = float(tmax.item())
     ms_per_step = elapsed / a.steps * 1e3
     total_flops = flops * (world if (a.workload != "moe" and world > 1) else 1)
     value = total_flops / (ms_per_step * 1e-3) / 1e12
 
+    # ------------------------------------------------------------------ expert-parallel phases (outside the timed region)
+    ep_roofline = None
+    if world > 1 and a.workload == "moe":
+        for ep in ep_objects:
+            ep.record_phases = True
+        for _ in range(max(4, min(20, a.steps))):
+            step()
+        torch.cuda.synchronize()
+        acc = {}
+        for ep in ep_objects:
+            for k, v in ep.phase_times_ms().items():
+                acc.setdefault(k, []).append(v)
+            ep.record_phases = False
+        mine = {k: sum(v) / len(v) for k, v in acc.items()}
+        names = sorted(mine)
+        t = torch.tensor([mine[k] for k in names], dtype=torch.float64, device=dev)
+        all_reduce_max(t)
+        extra["ep_phases_ms_max_over_ranks"] = {k: float(v) for k, v in zip(names, t.tolist())}
+        t_g = extra["ep_phases_ms_max_over_ranks"].get("regroup_and_grouped_gemm")
+        if t_g:
+            ach = flops / world / (t_g * 1e-3) / 1e12
+            ep_roofline = {"bound": "mfma", "kernel": "gemm_i8_kernel (local experts of one rank)", "achieved": ach,
+                           "peak": MFMA_I8_PEAK_TOPS, "unit": "TFLOP/s", "frac": ach / MFMA_I8_PEAK_TOPS, "traffic": None,
+                           "note": "per GPU: this rank's share of the algorithmic flops over its regroup + pre-pass + grouped "
+                                   "GEMM phase (GPU events, max over ranks); the step itself is all-to-all latency bound"}
+        extra["ep_phases_note"] = ("GPU-event time between phase boundaries of one expert-parallel step (dispatch / grouped GEMM / "
+                                   "combine reported separately, SURVEY 8d config 4); includes host gaps inside a phase")
+
     # ------------------------------------------------------------------ per-kernel durations (HIP events on the launch stream)
-    roofline = None
+    roofline = ep_roofline
     if phases is not None and world == 1:
         n = a.steps
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)]

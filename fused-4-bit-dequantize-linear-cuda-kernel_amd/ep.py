@@ -67,6 +67,8 @@ class ExpertParallelMoE:
         self.expert_fn = expert_fn
         self.out_features = out_features
         self.last_split = {}
+        self.record_phases = False      # set True to collect per-phase GPU events of the next device-path steps
+        self.phase_events = []          # one list of (name, torch.cuda.Event) per profiled step
 
     @staticmethod
     def shard(tensor: torch.Tensor, rank: int, world: int) -> torch.Tensor:
@@ -84,6 +86,14 @@ class ExpertParallelMoE:
         top_k = expert_indices.shape[1]
         dev = x.device
         K = x.shape[1]
+        marks = [] if self.record_phases else None
+
+        def mark(name):
+            if marks is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append((name, ev))
+        mark("start")
         counts, offsets, token_of_sorted, pos_of_slot = ops.route_plan(expert_indices, self.num_experts)
         fused_gather = hasattr(self.expert_fn, "gather") and K % 32 == 0 and x.dtype == torch.float32
         if G == 1:
@@ -95,6 +105,7 @@ class ExpertParallelMoE:
             send_rows = x.index_select(0, token_of_sorted.long())
             send_counts = counts.to(torch.int64)
             recv_counts = torch.empty(G * EL, dtype=torch.int64, device=dev)
+            mark("plan_and_pack")
             dist.all_to_all_single(recv_counts, send_counts, group=self.group)
             recv_counts = recv_counts.view(G, EL)
             # split sizes must be host integers for all_to_all_single: one small D2H copy per step
@@ -102,7 +113,9 @@ class ExpertParallelMoE:
             in_splits, out_splits = sizes[0].tolist(), sizes[1].tolist()
             R = sum(out_splits)
             recv_rows = torch.empty((R, K), dtype=x.dtype, device=dev)
+            mark("counts_exchange_and_host_sizes")
             dist.all_to_all_single(recv_rows, send_rows, out_splits, in_splits, group=self.group)
+            mark("dispatch_all_to_all")
             # received order is (source rank, local expert); the GEMM wants (local expert, source rank)
             tpe, offs, gather, scatter = ops.regroup_index(recv_counts, R)
             if R == 0:
@@ -113,12 +126,30 @@ class ExpertParallelMoE:
                 y_recv_order = self.expert_fn(recv_rows.index_select(0, gather.long()), tpe, offs).index_select(
                     0, scatter.long())
             y_sorted = torch.empty((send_rows.shape[0], y_recv_order.shape[1]), dtype=y_recv_order.dtype, device=dev)
+            mark("regroup_and_grouped_gemm")
             dist.all_to_all_single(y_sorted, y_recv_order.contiguous(), in_splits, out_splits, group=self.group)
+            mark("combine_all_to_all")
             self.last_split = {"dispatch_rows_sent": in_splits, "dispatch_rows_received": out_splits}
+        if G == 1:
+            mark("plan_and_grouped_gemm")
         if y_sorted.dtype == torch.float32 and x.shape[0] <= 65535:
-            return ops.combine(y_sorted, pos_of_slot, expert_weights)
-        y = y_sorted.index_select(0, pos_of_slot.long()).view(x.shape[0], top_k, -1)
-        return (y * expert_weights.unsqueeze(-1).to(y.dtype)).sum(dim=1)
+            out = ops.combine(y_sorted, pos_of_slot, expert_weights)
+        else:
+            y = y_sorted.index_select(0, pos_of_slot.long()).view(x.shape[0], top_k, -1)
+            out = (y * expert_weights.unsqueeze(-1).to(y.dtype)).sum(dim=1)
+        mark("weighted_combine")
+        if marks is not None:
+            self.phase_events.append(marks)
+        return out
+
+    def phase_times_ms(self):
+        """Mean GPU time of each phase over the profiled steps (call after torch.cuda.synchronize())."""
+        acc, n = {}, 0
+        for marks in self.phase_events:
+            for (_, e0), (name, e1) in zip(marks[:-1], marks[1:]):
+                acc[name] = acc.get(name, 0.0) + e0.elapsed_time(e1)
+            n += 1
+        return {k: v / n for k, v in acc.items()} if n else {}
 
     def forward(self, x: torch.Tensor, expert_indices: torch.Tensor, expert_weights: torch.Tensor) -> torch.Tensor:
         """x [t_local, K] float32, expert_indices / expert_weights [t_local, top_k] -> [t_local, N]."""
