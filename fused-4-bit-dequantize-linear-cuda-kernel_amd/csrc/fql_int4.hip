@@ -67,8 +67,10 @@ struct TileShape { int bm, bn; };
     X(7, 2, 2, 1, 8, 4)        /*  64 x  64, 4 waves   workgroups per CU, 4 weight stages in flight, deep */ \
     X(8, 1, 2, 1, 8, 4)        /*  32 x  64, 2 waves   A ring to cover L2 latency) */ \
     X(9, 2, 4, 3, 2, 1)        /*  64 x 384: 64-row groups with the A-fragment reuse of the 128 x 192 tile */ \
-    X(10, 2, 4, 3, 4, 2)       /*  64 x 384, 2 weight stages in flight (1- and 2-limb register budgets) */
-constexpr int FQL_NUM_CFG = 11;
+    X(10, 2, 4, 3, 4, 2)       /*  64 x 384, 2 weight stages in flight (1- and 2-limb register budgets) */ \
+    X(11, 2, 4, 3, 8, 2)       /*  64 x 384, full-stage A ring (every load one stage ahead), 2 weight stages */ \
+    X(12, 4, 2, 3, 8, 2)       /* 128 x 192, full-stage A ring, 2 weight stages */
+constexpr int FQL_NUM_CFG = 13;
 // Short row groups (fql_gemm_rows32.h): 32-row tiles, K split KG ways inside the workgroup.  ids 100 + i.
 // R(i, NF, KG, A-ring depth in k-steps, weight stages in flight per wave, waves per SIMD)
 #define FQL_ROWS32_LIST(R)                                                                                         \
@@ -272,13 +274,14 @@ inline int choose_cfg(int L, int E, int T, int K, int N, bool grouped)
     }
     if (m <= 16) return 202;                                 //  16 x 128 decode tiles: every load one stage ahead
     if (m <= 32) return 100;                                 //  32 x 128, K split 4 ways inside the workgroup
-    if (m <= 64) return 9;                                   //  64 x 384
+    if (m <= 64) return (L <= 2) ? 11 : 9;                   //  64 x 384 (1 / 2 limbs: full-stage activation ring)
     const int mt = groups * ((m + 127) / 128);
     struct Cand { int cfg, bn; };
     // 3 limbs: 128 x 192 with a 2-step A ring (register budget) / 128 x 128; 2 limbs: 4-step ring, + 128 x 256
     const Cand c3[2] = {{0, 192}, {1, 128}};
     const Cand c2[3] = {{3, 192}, {1, 128}, {2, 256}};
-    const Cand *cands = (L <= 2) ? c2 : c3;
+    const Cand c1[3] = {{12, 192}, {1, 128}, {2, 256}};      // 1 limb: registers allow the full-stage activation ring
+    const Cand *cands = (L == 1) ? c1 : (L == 2) ? c2 : c3;
     const int nc = (L <= 2) ? 3 : 2;
     int best = cands[0].cfg;
     long long best_cost = -1;

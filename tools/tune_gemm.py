@@ -37,7 +37,7 @@ def main():
     tune.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [ctypes.c_void_p]
     ncfg = lib.fql_tune_num_configs()
     cfgs = [int(c) for c in a.cfgs.split(",")] if a.cfgs else list(range(ncfg))
-    prec = {"exact": 3, "fast": 2}[a.precision]
+    prec = {"exact": 3, "fast": 2, "int8": 1}[a.precision]
     E, K, N = a.experts, a.hidden, a.ffn
 
     g = torch.Generator(device=dev).manual_seed(1)
