@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the product calls against the C oracle (run on a GPU box; not part of the test
+suite: tests/ holds the fixed cases).  Exercises every dispatch branch: GEMV, generic, wide / short-row / decode
+tiles, grouped and dense, the three precisions and the 16-bit I/O."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np, torch
+import fused_int4_amd as fq
+from fused_int4_amd import ops
+from oracle import oracle as O, c_oracle as C
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+rng = np.random.default_rng(2024)
+TOL = {"exact": 2e-6, "fast": 2e-4, "int8": 1.5e-2}
+worst = {}
+def rel(a, b):
+    d = np.linalg.norm(b.astype(np.float64)); return np.linalg.norm(a.astype(np.float64) - b) / (d if d else 1.0)
+for case in range(n_cases):
+    prec = ["exact", "fast", "int8"][case % 3]
+    K = int(rng.choice([32, 64, 96, 256, 544, 768, 1024, 34, 4096])) if case % 7 else int(rng.integers(1, 40)) * 2
+    N = int(rng.choice([5, 17, 64, 96, 200, 264, 1000, 1024]))
+    grouped = case % 2 == 0
+    if grouped:
+        E = int(rng.choice([1, 2, 3, 8, 17, 70]))
+        hi = int(rng.choice([3, 17, 40, 150]))
+        counts = rng.integers(0, hi, size=E).astype(np.int32)
+        if rng.random() < 0.3: counts[rng.integers(0, E)] = 0
+        gap = int(rng.integers(0, 4))
+        offs = (np.cumsum(counts) - counts).astype(np.int32)
+        T = int(counts.sum()) + gap
+        if T == 0: continue
+        P, S, Z = [], [], []
+        for e in range(E):
+            p, s, z = O.quantize_weights((rng.standard_normal((N, K)) * 0.05).astype(np.float32))
+            P.append(p); S.append(s); Z.append(z)
+        P, S, Z = np.stack(P), np.stack(S), np.stack(Z)
+        x = rng.standard_normal((T, K)).astype(np.float32)
+        ref = C.moe_grouped(P, S, Z, x, counts, offs)
+        d = lambda a: torch.from_numpy(a).cuda()
+        out = ops.moe_forward(d(P), d(S), d(Z), d(x), None, d(counts), d(offs), precision=prec).cpu().numpy()
+        key = f"moe/{prec}"
+        if K % 32 == 0 and case % 4 == 0:
+            h = ops.moe_forward_any(d(P), d(S), d(Z), d(x).half(), None, d(counts), d(offs), precision=prec)
+            w = ops.moe_forward(d(P), d(S), d(Z), d(x).half().float(), None, d(counts), d(offs), precision=prec).half()
+            assert torch.equal(h, w), ("f16 io", case, E, N, K, counts)
+    else:
+        B = int(rng.choice([1, 2, 3, 4, 5, 9, 16, 17, 33, 64, 130]))
+        p, s, z = O.quantize_weights((rng.standard_normal((N, K)) * 0.05).astype(np.float32))
+        x = rng.standard_normal((B, K)).astype(np.float32)
+        ref = C.linear_f64acc(x, p, s, z)
+        d = lambda a: torch.from_numpy(a).cuda()
+        out = ops.linear_forward(d(x), d(p), d(s), d(z), precision=prec).cpu().numpy()
+        key = f"linear/{prec}"
+    mfma = (K % 32 == 0) and (grouped or x.shape[0] > 4)
+    tol = TOL[prec] if mfma else 2e-6
+    if mfma and prec == "int8" and out.size < 2000:
+        tol = 6e-2                      # 8-bit activations: few outputs -> the relative Frobenius error is noisy
+    r = rel(out, ref)
+    worst[key] = max(worst.get(key, 0.0), r)
+    assert r < tol, (case, key, r, K, N, x.shape)
+print("cases", n_cases, "worst relative error per path:", {k: f"{v:.2e}" for k, v in sorted(worst.items())})
