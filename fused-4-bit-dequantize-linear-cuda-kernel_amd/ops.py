@@ -410,7 +410,7 @@ def dequantize_forward(packed_weights, scales, zero_points):
     return w
 
 
-def act_quant(x, precision="default", tokens_per_expert=None, input_offsets=None):
+def act_quant(x, precision="default", tokens_per_expert=None, input_offsets=None, out=None):
     """Phase 1 of the MFMA path: float32 rows -> int8 limbs in MFMA-fragment order (+ delta, rowsum).
     Pass the device-side expert arrays for a grouped (MoE) layout, or neither for one group."""
     if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2:
@@ -422,9 +422,12 @@ def act_quant(x, precision="default", tokens_per_expert=None, input_offsets=None
     grouped = tokens_per_expert is not None
     E = tokens_per_expert.numel() if grouped else 1
     L = _native.lib()
-    limbs = torch.zeros(L.fql_act_limb_bytes(T, E, K, prec), dtype=torch.int8, device=x.device)
-    delta = torch.empty((T,), dtype=torch.float32, device=x.device)
-    rowsum = torch.empty((nl, T), dtype=torch.int32, device=x.device)
+    if out is not None:                 # reuse the buffers of an earlier call with the same shapes (timing loops)
+        limbs, delta, rowsum = out
+    else:
+        limbs = torch.zeros(L.fql_act_limb_bytes(T, E, K, prec), dtype=torch.int8, device=x.device)
+        delta = torch.empty((T,), dtype=torch.float32, device=x.device)
+        rowsum = torch.empty((nl, T), dtype=torch.int32, device=x.device)
     with torch.cuda.device(x.device):
         rc = L.fql_act_quant_f32(x.data_ptr(), limbs.data_ptr(), delta.data_ptr(), rowsum.data_ptr(),
                                  tokens_per_expert.data_ptr() if grouped else None,
