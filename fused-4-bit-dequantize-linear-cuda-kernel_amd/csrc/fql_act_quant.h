@@ -50,20 +50,24 @@ __device__ __forceinline__ int act_exponent(float m)
     return e;
 }
 
-// ---- single-launch pre-pass.  One 256-thread workgroup owns ACT_ROWS = 8 consecutive padded rows end to end:
-//      thread t holds row r = t & 7 and the 16-float chunks ch = (t >> 3) + 32 j of that row (K <= 4096: the
-//      workgroup's whole 128 KiB of x sits in registers, read from HBM exactly once, all loads in flight
-//      together).  Row max -> 3 xor-shuffles + 4-wave LDS combine -> delta; then every 16-float chunk becomes
-//      one 16-byte limb chunk per limb: k = 16 ch of the row IS lane group g / k-step ks of the fragment layout
-//      (see the header comment), and the 8 rows of a workgroup are 8 neighbouring lanes of the fragment, so
-//      each group of 8 threads stores one full 128-byte line.  No LDS staging of data, no second launch.
+// ---- single-launch pre-pass.  One 256-thread workgroup owns ACT_ROWS (4) consecutive padded rows end to end:
+//      thread t holds row r = t % ACT_ROWS and the 16-float chunks ch = t / ACT_ROWS + ACT_COLS j of that row
+//      (K <= 4096: the workgroup's whole 64 KiB of x sits in registers, read from HBM exactly once, all loads in
+//      flight together).  Row max -> xor-shuffles + 4-wave LDS combine -> delta; then every 16-float chunk
+//      becomes one 16-byte limb chunk per limb: k = 16 ch of the row IS lane group g / k-step ks of the fragment
+//      layout (see the header comment), and the rows of a workgroup are neighbouring lanes of the fragment, so
+//      each group of ACT_ROWS threads stores ACT_ROWS x 16 contiguous bytes.  No LDS staging of data, no second
+//      launch.
 //      Limb row sums by v_dot4 against 0x01010101, reduced the same way as the max.
 //      Rows longer than 4096 are processed in 4096-k slabs: pass 1 streams all slabs for the max, pass 2
 //      re-reads them (L2 hits: the workgroup just read them).
 //      Workgroups with blockIdx.x >= rblocks (MoE entry point only) zero-fill the rows of `out` no expert
 //      covers (reference semantics: torch::zeros, csrc/moe_int4_kernel.cu:109).
-#define ACT_ROWS 8
-#define ACT_CH 8              // chunks per thread per slab: 32 chunk columns x 8 = 256 chunks = 4096 k
+#ifndef ACT_ROWS
+#define ACT_ROWS 4                  // measured: 8 rows 15.0 us, 4 rows 12.4 us, 2 rows 12.4 us at configs[2]
+#endif
+#define ACT_COLS (256 / ACT_ROWS)   // chunk columns of the 256 threads
+#define ACT_CH (256 / ACT_COLS)     // chunks per thread per slab: ACT_COLS x ACT_CH = 256 chunks = 4096 k
 
 // IN: element type of x (FQL_DTYPE_F32 / _F16 / _BF16); 16-bit inputs are widened in registers (exact), so the
 // limbs are the ones the float32 copy of x would give.  out_es: bytes per element of `out` (zero fill only).
@@ -149,24 +153,24 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
     if (p0 >= total) return;                      // past the last expert's rows (uniform per workgroup)
     __syncthreads();
 
-    const int r = tid & 7, col = tid >> 3;        // row of the workgroup, chunk column 0..31
+    const int r = tid & (ACT_ROWS - 1), col = tid / ACT_ROWS;   // row of the workgroup, chunk column
     const int tok = s_tok[r];
     const int p = p0 + r, mb = p >> 5, r32 = p & 31;
     static_assert(!GATE || IN == 0, "the gated pre-pass takes float32 rows");
     const char *xr = reinterpret_cast<const char *>(xin) +
                      (size_t)(tok >= 0 ? source_row(gather, n_src, tok) : 0) * K * ES * (GATE ? 2 : 1);
     const int nch = KB * 16;                      // 16-float chunks per padded row
-    const int slabs = (nch + 32 * ACT_CH - 1) / (32 * ACT_CH);
+    const int slabs = (nch + ACT_COLS * ACT_CH - 1) / (ACT_COLS * ACT_CH);
 
     // VEC (K % 16 == 0, x 16-byte aligned; host-checked): every load is unconditional.  A chunk past K (the
     // zero padding up to a multiple of 256) or a padding row re-reads valid data -- duplicates do not move the
     // row max -- and is masked to +0.0f in pass 2.
     v4f xv[ACT_CH][4];
-    auto chunk_ok = [&](int slab, int j) { return tok >= 0 && (slab * 32 * ACT_CH + col + 32 * j) * 16 < K; };
+    auto chunk_ok = [&](int slab, int j) { return tok >= 0 && (slab * ACT_COLS * ACT_CH + col + ACT_COLS * j) * 16 < K; };
     auto load_slab = [&](int slab) {
 #pragma unroll
         for (int j = 0; j < ACT_CH; ++j) {
-            const int k0 = (slab * 32 * ACT_CH + col + 32 * j) * 16;
+            const int k0 = (slab * ACT_COLS * ACT_CH + col + ACT_COLS * j) * 16;
             if (VEC) {
                 const char *src = xr + (size_t)(k0 < K ? k0 : 0) * ES;
                 if (IN == 0 && GATE) {
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
                 }
     }
 #pragma unroll
-    for (int o = 8; o < 64; o <<= 1) {
+    for (int o = ACT_ROWS; o < 64; o <<= 1) {
         const uint32_t n = (uint32_t)__shfl_xor((int)mu, o, 64);
         mu = n > mu ? n : mu;
     }
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
         if (slabs > 1) load_slab(slab);
 #pragma unroll
         for (int j = 0; j < ACT_CH; ++j) {
-            const int ch = slab * 32 * ACT_CH + col + 32 * j;
+            const int ch = slab * ACT_COLS * ACT_CH + col + ACT_COLS * j;
             if (ch >= nch) continue;
             // All L balanced digits of X at once: Y = X + sum_{l<L-1} 128*256^l has plain base-256 digits
             // d_l + 128 in its low bytes and the top digit above them, so byte l of Z = Y ^ 0x..8080 is limb l.
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
 #pragma unroll
     for (int l = 0; l < L; ++l) {
 #pragma unroll
-        for (int o = 8; o < 64; o <<= 1) sums[l] += __shfl_xor(sums[l], o, 64);
+        for (int o = ACT_ROWS; o < 64; o <<= 1) sums[l] += __shfl_xor(sums[l], o, 64);
         if (lane < ACT_ROWS) s_sum[wave][lane][l] = sums[l];
     }
     __syncthreads();
