@@ -206,3 +206,63 @@ def test_balanced_routing():
     assert r.tokens_per_expert == [128] * 8
     assert (r.expert_indices[:, 0] != r.expert_indices[:, 1]).all()
     assert torch.allclose(r.expert_weights.sum(1), torch.ones(512))
+
+
+# ---- additions beyond the reference's surface: host-side behaviour that needs no GPU
+def test_new_ops_refuse_cpu_tensors():
+    """The product path has no CPU fallback: GPU-only ops raise on host tensors instead of computing something."""
+    from fused_int4_amd import ops
+    idx = torch.zeros(4, 2, dtype=torch.int64)
+    with pytest.raises(RuntimeError):
+        ops.route_plan(idx, 4)
+    with pytest.raises(RuntimeError):
+        ops.combine(torch.zeros(8, 16), torch.zeros(8, dtype=torch.int32), torch.ones(4, 2))
+    with pytest.raises(RuntimeError):
+        ops.moe_gated_forward(torch.zeros(1, 8, 16, dtype=torch.uint8), torch.ones(1, 8), torch.zeros(1, 8),
+                              torch.zeros(3, 64), torch.tensor([3]), torch.tensor([0]))
+    with pytest.raises(RuntimeError):
+        fq.QuantizedMoEFFN(2, 32, 64)(torch.zeros(4, 32), torch.tensor([2, 2]), torch.tensor([0, 2]))
+    with pytest.raises(ValueError):
+        ops._precision("bf16")
+
+
+def test_routing_helpers_cpu_formulation():
+    """dispatch_grouped / dispatch_indices / combine_grouped on CPU tensors (the torch formulation the device
+    kernels are tested against): round trip through an identity expert returns the routing-weighted tokens."""
+    torch.manual_seed(4)
+    T, E, top_k, K = 19, 5, 2, 8
+    x = torch.randn(T, K)
+    route = fq.simulate_routing(T, E, top_k, "random", "cpu", 3)
+    grouped, tpe, offs, inv = fq.dispatch_grouped(x, route.expert_indices, E)
+    ridx, tpe2, offs2, inv2 = fq.dispatch_indices(route.expert_indices, E)
+    assert torch.equal(tpe, tpe2) and torch.equal(offs, offs2) and torch.equal(inv, inv2)
+    assert torch.equal(grouped, x[ridx.long()])
+    assert int(tpe.sum()) == T * top_k and torch.equal(offs.long(), torch.cumsum(tpe.long(), 0) - tpe.long())
+    out = fq.combine_grouped(grouped, route.expert_weights, inv, top_k)
+    assert torch.allclose(out, x * route.expert_weights.sum(1, keepdim=True), atol=1e-6)
+
+
+def test_gated_ffn_oracle_matches_torch_float64():
+    """oracle.gated_ffn_grouped (test infrastructure for SURVEY 8f N4) against a direct torch float64 evaluation."""
+    torch.manual_seed(8)
+    E, H, F = 2, 32, 64
+    gate = [torch.randn(F, H) * 0.1 for _ in range(E)]
+    up = [torch.randn(F, H) * 0.1 for _ in range(E)]
+    down = [torch.randn(H, F) * 0.1 for _ in range(E)]
+    ffn = fq.QuantizedMoEFFN.from_weights(gate, up, down)
+    assert ffn.gate_up_packed.shape == (E, 2 * F, H // 2) and ffn.down_packed.shape == (E, H, F // 2)
+    counts = np.array([3, 5], dtype=np.int32)
+    offs = np.array([0, 3], dtype=np.int32)
+    x = torch.randn(8, H)
+    ref = O.gated_ffn_grouped(
+        tuple(b.numpy() for b in (ffn.gate_up_packed, ffn.gate_up_scales, ffn.gate_up_zero_points)),
+        tuple(b.numpy() for b in (ffn.down_packed, ffn.down_scales, ffn.down_zero_points)), x.numpy(), counts, offs)
+    want = torch.zeros(8, H, dtype=torch.float64)
+    for e in range(E):
+        wgu = dequantize_weights(ffn.gate_up_packed[e], ffn.gate_up_scales[e], ffn.gate_up_zero_points[e]).double()
+        wd = dequantize_weights(ffn.down_packed[e], ffn.down_scales[e], ffn.down_zero_points[e]).double()
+        rows = slice(int(offs[e]), int(offs[e] + counts[e]))
+        gu = x[rows].double() @ wgu.T
+        want[rows] = (torch.nn.functional.silu(gu[:, :F]) * gu[:, F:]) @ wd.T
+    assert np.allclose(ref, want.numpy(), rtol=1e-12, atol=1e-12)
+    assert ffn.total_memory_bytes == sum(b.numel() * b.element_size() for b in ffn.buffers())
