@@ -69,8 +69,9 @@ struct TileShape { int bm, bn; };
     X(9, 2, 4, 3, 2, 1)        /*  64 x 384: 64-row groups with the A-fragment reuse of the 128 x 192 tile */ \
     X(10, 2, 4, 3, 4, 2)       /*  64 x 384, 2 weight stages in flight (1- and 2-limb register budgets) */ \
     X(11, 2, 4, 3, 8, 2)       /*  64 x 384, full-stage A ring (every load one stage ahead), 2 weight stages */ \
-    X(12, 4, 2, 3, 8, 2)       /* 128 x 192, full-stage A ring, 2 weight stages */
-constexpr int FQL_NUM_CFG = 13;
+    X(12, 4, 2, 3, 8, 2)       /* 128 x 192, full-stage A ring, 2 weight stages */ \
+    X(13, 4, 1, 2, 4, 8)       /* 128 x  64, 4 waves, 8 weight stages in flight (few tall tiles: HBM-latency bound) */
+constexpr int FQL_NUM_CFG = 14;
 // Short row groups (fql_gemm_rows32.h): 32-row tiles, K split KG ways inside the workgroup.  ids 100 + i.
 // R(i, NF, KG, A-ring depth in k-steps, weight stages in flight per wave, waves per SIMD)
 #define FQL_ROWS32_LIST(R)                                                                                         \
@@ -270,7 +271,7 @@ inline int choose_cfg(int L, int E, int T, int K, int N, bool grouped)
         if (m <= 16) return 203;                             //  16 x 64 decode tiles, K split 8 ways (fql_gemm_rows16.h)
         if (m <= 32) return 8;                               //  32 x 64, 2 waves
         if (m <= 64) return 7;                               //  64 x 64, 4 waves
-        return 6;                                            // 128 x 64, 4 waves
+        return 13;                                           // 128 x 64, 4 waves, 8 weight stages in flight
     }
     if (m <= 16) return 202;                                 //  16 x 128 decode tiles: every load one stage ahead
     if (m <= 32) return 100;                                 //  32 x 128, K split 4 ways inside the workgroup

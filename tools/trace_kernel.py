@@ -8,7 +8,7 @@ import fused_int4_amd as fq
 from fused_int4_amd import ops, _native
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 m = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-dev = torch.device("cuda:0"); E, K, N = 8, 4096, 11008
+dev = torch.device("cuda:0"); E, K, N = (int(sys.argv[3]) if len(sys.argv) > 3 else 8), 4096, 11008
 g = torch.Generator(device=dev).manual_seed(0)
 sets = []
 for _ in range(3):
