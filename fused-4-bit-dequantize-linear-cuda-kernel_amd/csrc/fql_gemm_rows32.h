@@ -30,7 +30,10 @@ struct Rows32Cfg {
     static constexpr int SLAB = NF * 32 * (FQL_KB / 2);       // wave-private LDS bytes (one stage of packed weights)
     static constexpr int ACC_BYTES = L * NF * 16 * 64 * 4;    // one wave's accumulators
     static constexpr int RED_BYTES = (KG > 1) ? (KG / 2) * NG * ACC_BYTES : 0;   // first round of the K-group tree
-    static constexpr int LDS_BYTES = (NW * SLAB > RED_BYTES) ? NW * SLAB : RED_BYTES;
+    static constexpr int MAIN_BYTES = (NW * SLAB > RED_BYTES) ? NW * SLAB : RED_BYTES;
+    static constexpr int SZ_BYTES = 2 * 2 * BN * 4;           // scale / zero-point slices of two tiles
+    static constexpr int LDS_BYTES = MAIN_BYTES + SZ_BYTES;
+    static constexpr int SZN = (2 * BN + THREADS - 1) / THREADS;
     static_assert(KG == 1 || KG == 2 || KG == 4 || KG == 8, "K split");
     static_assert(KS % D == 0, "ring depth must divide the steps per stage");
     static_assert(LDS_BYTES * WG_PER_CU <= 160 * 1024, "LDS budget");
@@ -67,14 +70,21 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
     const int kg = wave / NG, ng = wave - kg * NG;            // this wave's K group and column group
     const int l31 = lane & 31, g = lane >> 5;
 
+    // ---- expert table: ONE pass over the device-side counts per workgroup, kept in LDS (first 64 experts; more
+    //      experts fall back to re-reading per tile): finding a tile's expert later costs no global load
+    __shared__ int s_lo[64], s_cnt[64], s_tex[64], s_pex[64];
     int n_real = m_slots * n_tiles;
     if (tpe != nullptr) {
         int cp = 0, ct = 0;
-        for (int base = 0; base < E; base += 64) (void)expert_chunk(tpe, offs, E, T, C::BM, base, lane, cp, ct);
+        for (int base = 0; base < E; base += 64) {
+            const ExpertLane x = expert_chunk(tpe, offs, E, T, C::BM, base, lane, cp, ct);
+            if (base == 0 && wave == 0) { s_lo[lane] = x.lo; s_cnt[lane] = x.cnt; s_tex[lane] = x.tile_excl; s_pex[lane] = x.pad_excl; }
+        }
         const int m_tiles = ct < m_slots ? ct : m_slots;
         n_real = m_tiles * n_tiles;
     }
     n_real = __builtin_amdgcn_readfirstlane(n_real);
+    __syncthreads();
 
     // ---- tile id -> (expert, 32-row block, column block); m-tile major so neighbours share activations in L2
     auto tile_params = [&](int vb) -> Rows32Tile {
@@ -88,19 +98,36 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
             tp.rows_valid = T - tp.row0;
             tp.ok = 1;
         } else {
-            int cp = 0, ct = 0;
-            for (int base = 0; base < E && !tp.ok; base += 64) {
-                const ExpertLane x = expert_chunk(tpe, offs, E, T, C::BM, base, lane, cp, ct);
-                const unsigned long long hit = __ballot(ms >= x.tile_excl && ms < x.tile_excl + x.tiles);
+            {   // first 64 experts from LDS (lane i looks at expert i)
+                const int lo = s_lo[lane], cnt = s_cnt[lane], te = s_tex[lane], pe = s_pex[lane];
+                const int tiles_e = (cnt + C::BM - 1) / C::BM;
+                const unsigned long long hit = __ballot(lane < E && ms >= te && ms < te + tiles_e);
                 if (hit) {
                     const int src = __ffsll((long long)hit) - 1;
-                    const int lo = __shfl(x.lo, src, 64), cnt = __shfl(x.cnt, src, 64);
-                    const int te = __shfl(x.tile_excl, src, 64), pe = __shfl(x.pad_excl, src, 64);
-                    tp.e = base + src;
-                    tp.row0 = lo + (ms - te) * C::BM;
-                    tp.prow0 = pe + (ms - te) * C::BM;
-                    tp.rows_valid = cnt - (ms - te) * C::BM;
+                    const int lo_s = __shfl(lo, src, 64), cnt_s = __shfl(cnt, src, 64);
+                    const int te_s = __shfl(te, src, 64), pe_s = __shfl(pe, src, 64);
+                    tp.e = src;
+                    tp.row0 = lo_s + (ms - te_s) * C::BM;
+                    tp.prow0 = pe_s + (ms - te_s) * C::BM;
+                    tp.rows_valid = cnt_s - (ms - te_s) * C::BM;
                     tp.ok = 1;
+                }
+            }
+            if (!tp.ok && E > 64) {
+                int cp = 0, ct = 0;
+                for (int base = 0; base < E && !tp.ok; base += 64) {
+                    const ExpertLane x = expert_chunk(tpe, offs, E, T, C::BM, base, lane, cp, ct);
+                    const unsigned long long hit = __ballot(ms >= x.tile_excl && ms < x.tile_excl + x.tiles);
+                    if (hit && base > 0) {
+                        const int src = __ffsll((long long)hit) - 1;
+                        const int lo = __shfl(x.lo, src, 64), cnt = __shfl(x.cnt, src, 64);
+                        const int te = __shfl(x.tile_excl, src, 64), pe = __shfl(x.pad_excl, src, 64);
+                        tp.e = base + src;
+                        tp.row0 = lo + (ms - te) * C::BM;
+                        tp.prow0 = pe + (ms - te) * C::BM;
+                        tp.rows_valid = cnt - (ms - te) * C::BM;
+                        tp.ok = 1;
+                    }
                 }
             }
         }
@@ -159,6 +186,34 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
     //      tile's reduction and epilogue hide the next tile's first HBM round trip
     v4i bst[BD][C::PIECES];
     v4i afr[D][L];
+    float szr[C::SZN];
+    int drow[1 + L];                                          // delta bits and limb row sums of this lane's row
+    float *szbuf = reinterpret_cast<float *>(lds + C::MAIN_BYTES);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)delta, 0, T * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)rowsum, 0, L * T * 4, 0x00020000);
+    // the tile's scale / zero-point slice and this lane's row values travel with the tile's first loads, so the
+    // epilogue issues no global load (a load there would queue behind the next tile's HBM prefetch)
+    auto issue_tile_consts = [&](const Rows32Tile &tp) {
+        const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(scales + (size_t)tp.e * N), 0, N * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(zps + (size_t)tp.e * N), 0, N * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < C::SZN; ++i) {
+            const int idx = tid + i * C::THREADS;
+            const bool is_s = idx < C::BN;
+            const int col = is_s ? idx : idx - C::BN;
+            const int so = (tp.ok && idx < 2 * C::BN) ? 0 : OOB;
+            const int vo = (tp.nt * C::BN + col) * 4;
+            const int vs = __builtin_amdgcn_raw_buffer_load_b32(rsS, is_s ? vo : OOB, so, 0);
+            const int vz = __builtin_amdgcn_raw_buffer_load_b32(rsZ, is_s ? OOB : vo, so, 0);
+            szr[i] = __builtin_bit_cast(float, vs | vz);
+        }
+        const int t = (tp.ok && l31 < tp.rows_valid) ? tp.row0 + l31 : 0;
+        drow[0] = __builtin_amdgcn_raw_buffer_load_b32(rsD, t * 4, 0, 0);
+#pragma unroll
+        for (int l = 0; l < L; ++l) drow[1 + l] = __builtin_amdgcn_raw_buffer_load_b32(rsR, (l * T + t) * 4, 0, 0);
+    };
     int ev = 0;
     FQL_STAMP(ev++);                                          // 0: kernel entry (after n_real)
     Rows32Tile cur = tile_params(blockIdx.x);
@@ -177,13 +232,23 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
 #pragma unroll
             for (int l = 0; l < L; ++l) afr[d][l] = __builtin_amdgcn_raw_buffer_load_b128(rsA, aoffl[l], so, 0);
         }
+        issue_tile_consts(cur);
     }
+    int parity = 0;
 
-  for (int vb = blockIdx.x; vb < n_real; vb += gridDim.x) {
+  for (int vb = blockIdx.x; vb < n_real; vb += gridDim.x, parity ^= 1) {
     FQL_STAMP(ev++);                                          // tile: start
     const Rows32Tile nxt = tile_params(vb + gridDim.x);
     FQL_STAMP(ev++);                                          // tile: next params known
     const __amdgpu_buffer_rsrc_t rs_cur = w_rsrc(cur), rs_nxt = w_rsrc(nxt);
+    float *sz = szbuf + parity * 2 * C::BN;
+#pragma unroll
+    for (int i = 0; i < C::SZN; ++i)
+        if (tid + i * C::THREADS < 2 * C::BN) sz[tid + i * C::THREADS] = szr[i];
+    const float d = __builtin_bit_cast(float, drow[0]);
+    float rsum[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) rsum[l] = (float)drow[1 + l];
 
     v16i acc[L][NF];
 #pragma unroll
@@ -203,6 +268,7 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
         // fragment reads
 #pragma unroll
         for (int i = 0; i < C::PIECES; ++i) *reinterpret_cast<v4i *>(slab + wB[i]) = bst[u][i];
+        if (s + 1 == SP) issue_tile_consts(nxt);              // before the younger HBM loads of this boundary
         {   // refill the slot with the stage BD ahead (the next tile's first stages near the end of this one)
             const bool here = s + BD < SP;
             const int so = here ? w_soff(cur, s + BD) : w_soff(nxt, s + BD - SP);
@@ -289,6 +355,8 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
             }
         }
         __syncthreads();                                      // the next tile's slabs overwrite the partials
+    } else {
+        __syncthreads();                                      // the scale slice parked by other waves
     }
 
     FQL_STAMP(ev++);                                          // tile: reduction done
@@ -296,36 +364,15 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
     const Rows32Tile done = cur;
     cur = nxt;
     if (kg != 0 || !done.ok || l31 >= done.rows_valid) continue;
-    const int n0 = done.nt * C::BN + ng * NF * 32;
     const int t = done.row0 + l31;
-    const float d = delta[t];
-    float rsum[L];
-#pragma unroll
-    for (int l = 0; l < L; ++l) rsum[l] = (float)rowsum[(size_t)l * T + t];
-    const float *sce = scales + (size_t)done.e * N;
-    const float *zpe = zps + (size_t)done.e * N;
     const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & (out_kind == 0 ? 15 : 7)) == 0);
-    const bool vec_sz = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(sce) & 15) == 0) &&
-                        ((reinterpret_cast<uintptr_t>(zpe) & 15) == 0);
 #pragma unroll
     for (int j = 0; j < NF; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int n = n0 + j * 32 + 8 * q + 4 * g;
-            if (n >= N) continue;
-            float s4[4], z4[4];
-            if (vec_sz) {
-                const v4f sv = *reinterpret_cast<const v4f *>(sce + n);
-                const v4f zv = *reinterpret_cast<const v4f *>(zpe + n);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { s4[c] = sv[c]; z4[c] = zv[c]; }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    s4[c] = (n + c < N) ? sce[n + c] : 0.0f;
-                    z4[c] = (n + c < N) ? zpe[n + c] : 0.0f;
-                }
-            }
+            const int c0 = (ng * NF + j) * 32 + 8 * q + 4 * g;            // column inside the tile
+            const v4f s4 = *reinterpret_cast<const v4f *>(sz + c0);
+            const v4f z4 = *reinterpret_cast<const v4f *>(sz + C::BN + c0);
             float o[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -335,7 +382,7 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
                     tot = fmaf(tot, 256.0f, fmaf(-z4[c], rsum[l], (float)acc[l][j][4 * q + c]));
                 o[c] = (tot * d) * s4[c];
             }
-            store_out4(out, out_kind, (size_t)t * N, n, N, vec, o);
+            store_out4(out, out_kind, (size_t)t * N, done.nt * C::BN + c0, N, vec, o);
         }
   }
 #endif

@@ -274,7 +274,7 @@ inline int choose_cfg(int L, int E, int T, int K, int N, bool grouped)
         return 13;                                           // 128 x 64, 4 waves, 8 weight stages in flight
     }
     if (m <= 16) return 202;                                 //  16 x 128 decode tiles: every load one stage ahead
-    if (m <= 32) return 100;                                 //  32 x 128, K split 4 ways inside the workgroup
+    if (m <= 32) return 103;                                 //  32 x 128, K split 4 ways inside the workgroup
     if (m <= 64) return (L <= 2) ? 11 : 9;                   //  64 x 384 (1 / 2 limbs: full-stage activation ring)
     const int mt = groups * ((m + 127) / 128);
     struct Cand { int cfg, bn; };
