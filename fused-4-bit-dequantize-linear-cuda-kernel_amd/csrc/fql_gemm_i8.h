@@ -54,6 +54,10 @@ __device__ unsigned long long fql_trace_wide[8 * 64];
 #define FQL_WSTAMP(i, real) do { } while (0)
 #endif
 
+#ifndef FQL_WIDE_W_AUX
+#define FQL_WIDE_W_AUX 0       // cache policy of the wide kernel's weight loads (experiment hook; 2 = nt)
+#endif
+
 struct GemmTile {              // wave-uniform description of one BM x BN tile
     int e, row0, prow0, rows_valid, nt, ok;
 };
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
             (void *)(packed + (size_t)tp.e * wbytes), 0, (int)wbytes, 0x00020000);
         const int sB = tp.ok ? tp.nt * C::BN * (K >> 1) : OOB;
 #pragma unroll
-        for (int i = 0; i < C::CPWB; ++i) bst[0][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voffB0, sB + i * pieceB, 0);
+        for (int i = 0; i < C::CPWB; ++i) bst[0][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voffB0, sB + i * pieceB, FQL_WIDE_W_AUX);
         const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(scales + (size_t)tp.e * N), 0, N * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     for (int s = 1; s <= BD; ++s)
 #pragma unroll
         for (int i = 0; i < C::CPWB; ++i)
-            bst[s % BD][i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB0, (s < KT ? sB + s * (FQL_KB / 2) : OOB) + i * pieceB, 0);
+            bst[s % BD][i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB0, (s < KT ? sB + s * (FQL_KB / 2) : OOB) + i * pieceB, FQL_WIDE_W_AUX);
 
     if (active) {
         // ---- the weight fragments are software-pipelined one k-step ahead: the ds_reads of the next 64-k
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
 #pragma unroll
                     for (int i = 0; i < C::CPWB; ++i)
                         bst[(kk + 1) % BD][i] =
-                            __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB0, sNext + i * pieceB, 0);
+                            __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB0, sNext + i * pieceB, FQL_WIDE_W_AUX);
                 }
                 if (ks == 5) {
                     wait_lgkmcnt0();
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
 #pragma unroll
             for (int i = 0; i < C::CPWB; ++i)
                 bst[(kk + 1) % BD][i] =
-                    __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB0, sNext + i * pieceB, 0);
+                    __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB0, sNext + i * pieceB, FQL_WIDE_W_AUX);
             wait_lgkmcnt0();
             __builtin_amdgcn_s_barrier();
           }
