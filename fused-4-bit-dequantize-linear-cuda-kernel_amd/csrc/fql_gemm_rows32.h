@@ -15,6 +15,10 @@
 #include "fql_common.h"
 #include "fql_gemm_i8.h"
 
+#ifndef FQL_R32_W_AUX
+#define FQL_R32_W_AUX 2        // cache policy of the weight-stream loads: nt (read once; -2 % measured)
+#endif
+
 template <int L, int NF, int KG, int DEPTH, int BDEPTH, int OCC = 2>
 struct Rows32Cfg {
     static constexpr int NW = 8;
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
         for (int u = 0; u < BD; ++u) {
             const int so = w_soff(cur, u);
 #pragma unroll
-            for (int i = 0; i < C::PIECES; ++i) bst[u][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vrel[i], so, 0);
+            for (int i = 0; i < C::PIECES; ++i) bst[u][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vrel[i], so, FQL_R32_W_AUX);
         }
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -274,10 +278,10 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
             const int so = here ? w_soff(cur, s + BD) : w_soff(nxt, s + BD - SP);
             if (here) {
 #pragma unroll
-                for (int i = 0; i < C::PIECES; ++i) bst[u][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, vrel[i], so, 0);
+                for (int i = 0; i < C::PIECES; ++i) bst[u][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_cur, vrel[i], so, FQL_R32_W_AUX);
             } else {
 #pragma unroll
-                for (int i = 0; i < C::PIECES; ++i) bst[u][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_nxt, vrel[i], so, 0);
+                for (int i = 0; i < C::PIECES; ++i) bst[u][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_nxt, vrel[i], so, FQL_R32_W_AUX);
             }
         }
         v4i braw[NF];
