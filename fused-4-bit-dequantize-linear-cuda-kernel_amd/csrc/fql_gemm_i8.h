@@ -6,17 +6,22 @@
 // for every row t of expert e's range.  The inner integer dot products are exact (i32
 // accumulation), so results do not depend on tile shape, K order or which GPU ran the row.
 //
-// One workgroup = 8 waves (WM x WN), tile BM = 32*WM rows x BN = 32*NF*WN columns, 1 workgroup per CU:
+// One workgroup = 8 waves (WM x WN; 4 or 2 for the skinny tiles), tile BM = 32*WM rows x BN = 32*NF*WN columns,
+// persistent launch (one 8-wave workgroup per CU walks its tiles):
 //   * packed weights (the HBM stream, read once): 8 rows x 128 B = 8 FULL cache lines per wave
-//     instruction, global -> VGPR -> LDS one 256-k stage ahead (two LDS stages, XOR-swizzled so the
+//     instruction, global -> VGPR ring (BD stages) -> LDS (two LDS stages, XOR-swizzled so the
 //     fragment reads are bank-conflict-free); read back with one ds_read_b128 per 32 columns x 64 k;
 //     nibbles are unpacked in registers with 3 VALU ops per 8 weights (unpack8) straight into the MFMA
-//     B operand.
+//     operand, one k-step ahead of the MFMAs that use them.
 //   * activation limbs (re-read per column tile, served by the XCD's L2): the pre-pass stores them in
 //     MFMA-fragment order, so a wave's A operand for one 32-deep k-step is ONE coalesced 1 KiB
 //     buffer_load_dwordx4 straight into VGPRs -- no LDS round trip, no LDS-DMA (whose ~25 B/clk/CU
-//     ceiling and ~100-cycle issue cost capped the earlier LDS-staged version); a 4-step register ring
-//     keeps 4 k-steps of A in flight per wave.
+//     ceiling and ~100-cycle issue cost capped the earlier LDS-staged version); a D-step register ring
+//     keeps D k-steps of A in flight per wave (2 at 3 limbs -- the register budget -- up to a full stage of
+//     8 at 1 or 2 limbs, where it removes the waits behind the in-order HBM loads).
+//   * the weights are the MFMA's A operand, so every lane owns one output row: 16-byte stores; the next
+//     tile's first weight stage and its scale / zero-point slice (through LDS) are issued before the
+//     current tile's epilogue.
 //   * every load is an ordinary buffer load, so hipcc's own counted s_waitcnt vmcnt(N) tracks them;
 //     one workgroup barrier per 256-k stage (8 MFMA k-steps).
 //
