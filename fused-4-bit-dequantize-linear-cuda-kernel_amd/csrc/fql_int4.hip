@@ -70,8 +70,12 @@ struct TileShape { int bm, bn; };
     X(10, 2, 4, 3, 4, 2)       /*  64 x 384, 2 weight stages in flight (1- and 2-limb register budgets) */ \
     X(11, 2, 4, 3, 8, 2)       /*  64 x 384, full-stage A ring (every load one stage ahead), 2 weight stages */ \
     X(12, 4, 2, 3, 8, 2)       /* 128 x 192, full-stage A ring, 2 weight stages */ \
-    X(13, 4, 1, 2, 4, 8)       /* 128 x  64, 4 waves, 8 weight stages in flight (few tall tiles: HBM-latency bound) */
-constexpr int FQL_NUM_CFG = 14;
+    X(13, 4, 1, 2, 4, 8)       /* 128 x  64, 4 waves, 8 weight stages in flight (few tall tiles: HBM-latency bound) */ \
+    X(14, 4, 1, 3, 2, 1)       /* 128 x  96, 4 waves: TWO independent workgroups per CU, one wave per SIMD each, so one */ \
+    X(15, 2, 2, 3, 2, 1)       /*  64 x 192, 4 waves   workgroup's prologue / epilogue / barrier waits sit under the other's MFMAs */ \
+    X(16, 4, 1, 3, 2, 2)       /* 128 x  96, 4 waves, 2 weight stages in flight */ \
+    X(17, 4, 1, 2, 4, 2)       /* 128 x  64, 4 waves, 4-step A ring */
+constexpr int FQL_NUM_CFG = 18;
 // Short row groups (fql_gemm_rows32.h): 32-row tiles, K split KG ways inside the workgroup.  ids 100 + i.
 // R(i, NF, KG, A-ring depth in k-steps, weight stages in flight per wave, waves per SIMD)
 #define FQL_ROWS32_LIST(R)                                                                                         \

@@ -90,3 +90,14 @@ def decode_limbs(limbs_bytes, L, T, E, K, Kp, counts=None, offsets=None):
                         for i in range(8):
                             out[:, t, k0 + 8 * h + perm8[i]] = sixteen[:, 8 * h + i]
     return out, covered
+
+
+def row_quantum_bound(x, L):
+    """Predicted relative output error of each row from the one rounding of its activations to the row's
+    fixed-point quantum: delta[t] / sqrt(12) * sqrt(K) / ||x_t||_2 (rounding errors uniform in +-delta/2 and
+    uncorrelated with the weights).  Never above 2^-(8L-2) * sqrt(K/12): max|x_t| <= ||x_t||_2."""
+    x = np.asarray(x, dtype=np.float32)
+    _, delta, _ = act_limbs_reference(x, L)
+    nrm = np.linalg.norm(x.astype(np.float64), axis=1)
+    nrm[nrm == 0] = 1.0
+    return delta.astype(np.float64) / np.sqrt(12.0) * np.sqrt(x.shape[1]) / nrm
