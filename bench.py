@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="moe", choices=["moe", "linear512", "linear1"])
-    ap.add_argument("--precision", default="default", choices=["default", "exact", "fast", "int8"])
+    ap.add_argument("--precision", default="default", choices=["default", "exact", "fast", "int8", "fp8"])
     ap.add_argument("--routing", default="balanced", choices=["balanced", "skewed"])
     ap.add_argument("--weight-sets", type=int, default=4,
                     help="distinct weight copies rotated through so that consecutive steps cannot be served "
@@ -161,7 +161,7 @@ def main():
 
     E, K, N = a.experts, a.hidden, a.ffn
     prec = a.precision
-    limbs = {"fast": 2, "int8": 1}.get(prec, 3)
+    limbs = {"fast": 2, "int8": 1, "fp8": 1}.get(prec, 3)
     extra = {}
 
     def barrier():

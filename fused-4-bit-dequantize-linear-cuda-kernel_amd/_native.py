@@ -22,6 +22,7 @@ DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
 PRECISION_INT8 = 1
 PRECISION_FAST = 2
 PRECISION_EXACT = 3
+PRECISION_FP8 = 8
 
 _SYMBOLS = {
     # name: (restype, argtypes)
@@ -51,6 +52,8 @@ _SYMBOLS = {
     "fql_native_dtype_supported": (ctypes.c_int, [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_int]),
     "fql_linear_fwd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5
                        + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "fql_moe_fwd_f8": (ctypes.c_int, [ctypes.c_void_p] * 8 + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "fql_linear_fwd_f8": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "fql_moe_fwd": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 6
                     + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
 }

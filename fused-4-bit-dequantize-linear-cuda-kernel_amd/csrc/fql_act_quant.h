@@ -83,7 +83,80 @@ __device__ __forceinline__ float act_widen(unsigned short h)
 // second GEMM's pre-pass, so the [T, K] hidden activation is never materialised.
 __device__ __forceinline__ float act_silu_mul(float g, float u) { return (g / (1.0f + expf(-g))) * u; }
 
-template <int L, bool VEC, int IN, bool GATE = false>
+// ---- pieces shared by the pre-pass kernels (this file and fql_act_f8.h)
+// Coverage workgroups (MoE entry points only): zero-fill the rows of `out` no expert covers, 256 rows each
+// (reference semantics: torch::zeros, csrc/moe_int4_kernel.cu:109).
+__device__ __forceinline__ void act_zero_uncovered(int block, void *__restrict__ out, int out_es, int N,
+                                                   const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
+                                                   int E, int T)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int t = block * 256 + tid;
+    bool covered = false;
+    int cp = 0, ct = 0;
+    for (int base = 0; base < E; base += 64) {
+        const ExpertLane xl = expert_chunk(tpe, offs, E, T, FQL_MB, base, lane, cp, ct);
+        const int ne = (E - base) < 64 ? (E - base) : 64;
+        for (int i = 0; i < ne; ++i) {
+            const int lo = __shfl(xl.lo, i, 64), cnt = __shfl(xl.cnt, i, 64);
+            covered |= (t >= lo && t < lo + cnt);
+        }
+    }
+    if (t < T && !covered) {                             // rare path: rows no expert owns
+        if (out_es == 4) {
+            float *orow = reinterpret_cast<float *>(out) + (size_t)t * N;
+            for (int i = 0; i < N; ++i) orow[i] = 0.0f;
+        } else {
+            unsigned short *orow = reinterpret_cast<unsigned short *>(out) + (size_t)t * N;
+            for (int i = 0; i < N; ++i) orow[i] = 0;
+        }
+    }
+}
+
+// Token row of each of the workgroup's ACT_ROWS padded rows p0 .. (-1: padding) into s_tok; returns the number of
+// padded rows in use.  The caller synchronises before reading s_tok.
+struct ActLookupShared { int lo[64], cnt[64], pad[64], total; };
+__device__ __forceinline__ int act_token_rows(int p0, int rows, int *s_tok, ActLookupShared &sh,
+                                              const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
+                                              int E, int T)
+{
+    const int tid = threadIdx.x;
+    int total;
+    if (tpe == nullptr) {
+        if (tid < rows) s_tok[tid] = (p0 + tid < T) ? p0 + tid : -1;
+        total = (T + FQL_MB - 1) / FQL_MB * FQL_MB;
+    } else {
+        int t_found = -1;
+        int cp = 0, ct = 0;
+        total = 0;
+        for (int base = 0; base < E; base += 64) {
+            if (tid < 64) {
+                const ExpertLane xl = expert_chunk(tpe, offs, E, T, FQL_MB, base, tid, cp, ct);
+                sh.lo[tid] = xl.lo; sh.cnt[tid] = xl.cnt; sh.pad[tid] = xl.pad_excl;
+                if (tid == 0) sh.total = cp;              // running padded-row total
+            }
+            __syncthreads();
+            if (tid < rows && t_found < 0) {
+                const int p = p0 + tid;
+                const int ne = (E - base) < 64 ? (E - base) : 64;
+                for (int i = 0; i < ne; ++i) {
+                    const int rel = p - sh.pad[i];
+                    if (rel >= 0 && rel < sh.cnt[i]) { t_found = sh.lo[i] + rel; break; }
+                }
+            }
+            total = sh.total;
+            __syncthreads();
+        }
+        if (tid < rows) s_tok[tid] = t_found;
+    }
+    return total;
+}
+
+// F8OUT (L = 1): the row is scaled by 448 / max|x| and rounded to OCP e4m3 (round to nearest even) instead of being
+// split into int8 limbs -- the "fp8 activations" mode (FQL_PRECISION_FP8, BASELINE.json configs[4]).  delta[t] is the
+// float32 quotient max|x| / 448, the stored byte the conversion of the float32 quotient x / delta[t]; rowsum[0][t]
+// holds sum_k of the ROUNDED values as float32 bits (summed exactly as integers in units of 2^-9).
+template <int L, bool VEC, int IN, bool GATE = false, bool F8OUT = false>
 __global__ __launch_bounds__(256) void act_fused_kernel(
     const void *__restrict__ xin, const int32_t *__restrict__ gather, int n_src, float *__restrict__ delta,
     int32_t *__restrict__ rowsum, int8_t *__restrict__ limbs, int T, int K, int KB, int MBT, int rblocks,
@@ -94,62 +167,19 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
     __shared__ int s_tok[ACT_ROWS];
     __shared__ uint32_t s_max[4][ACT_ROWS];
     __shared__ int s_sum[4][ACT_ROWS][L];
-    __shared__ int s_lo[64], s_cnt[64], s_pad[64], s_total;
+    __shared__ long long s_sum8[4][ACT_ROWS];
+    __shared__ ActLookupShared s_lookup;
+    static_assert(!F8OUT || L == 1, "fp8 activations are one byte plane");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     if ((int)blockIdx.x >= rblocks) {             // ---- coverage workgroups: 256 rows of `out` each
-        const int t = ((int)blockIdx.x - rblocks) * 256 + tid;
-        bool covered = false;
-        int cp = 0, ct = 0;
-        for (int base = 0; base < E; base += 64) {
-            const ExpertLane xl = expert_chunk(tpe, offs, E, T, FQL_MB, base, lane, cp, ct);
-            const int ne = (E - base) < 64 ? (E - base) : 64;
-            for (int i = 0; i < ne; ++i) {
-                const int lo = __shfl(xl.lo, i, 64), cnt = __shfl(xl.cnt, i, 64);
-                covered |= (t >= lo && t < lo + cnt);
-            }
-        }
-        if (t < T && !covered) {                             // rare path: rows no expert owns
-            if (out_es == 4) {
-                float *orow = reinterpret_cast<float *>(out) + (size_t)t * N;
-                for (int i = 0; i < N; ++i) orow[i] = 0.0f;
-            } else {
-                unsigned short *orow = reinterpret_cast<unsigned short *>(out) + (size_t)t * N;
-                for (int i = 0; i < N; ++i) orow[i] = 0;
-            }
-        }
+        act_zero_uncovered((int)blockIdx.x - rblocks, out, out_es, N, tpe, offs, E, T);
         return;
     }
 
     // ---- token row of each of the workgroup's padded rows (-1: padding); total = padded rows in use
     const int p0 = blockIdx.x * ACT_ROWS;
-    int total;
-    if (tpe == nullptr) {
-        if (tid < ACT_ROWS) s_tok[tid] = (p0 + tid < T) ? p0 + tid : -1;
-        total = (T + FQL_MB - 1) / FQL_MB * FQL_MB;
-    } else {
-        int t_found = -1;
-        int cp = 0, ct = 0;
-        for (int base = 0; base < E; base += 64) {
-            if (tid < 64) {
-                const ExpertLane xl = expert_chunk(tpe, offs, E, T, FQL_MB, base, tid, cp, ct);
-                s_lo[tid] = xl.lo; s_cnt[tid] = xl.cnt; s_pad[tid] = xl.pad_excl;
-                if (tid == 0) s_total = cp;               // running padded-row total
-            }
-            __syncthreads();
-            if (tid < ACT_ROWS && t_found < 0) {
-                const int p = p0 + tid;
-                const int ne = (E - base) < 64 ? (E - base) : 64;
-                for (int i = 0; i < ne; ++i) {
-                    const int rel = p - s_pad[i];
-                    if (rel >= 0 && rel < s_cnt[i]) { t_found = s_lo[i] + rel; break; }
-                }
-            }
-            total = s_total;
-            __syncthreads();
-        }
-        if (tid < ACT_ROWS) s_tok[tid] = t_found;
-    }
+    const int total = act_token_rows(p0, ACT_ROWS, s_tok, s_lookup, tpe, offs, E, T);
     if (p0 >= total) return;                      // past the last expert's rows (uniform per workgroup)
     __syncthreads();
 
@@ -242,6 +272,51 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
     }
     const bool bad = mu >= 0x7F800000u;
     const float m = __uint_as_float(mu);
+    if constexpr (F8OUT) {
+        // ---- pass 2 (fp8): y = x / scale rounded to e4m3, scale = max|x| / 448 (1 for an all-zero row)
+        const float scale = (bad || m == 0.0f) ? 1.0f : m / 448.0f;
+        if (tid < ACT_ROWS && tok >= 0) delta[tok] = bad ? __builtin_nanf("") : scale;
+        long long sum8 = 0;
+        for (int slab = 0; slab < slabs; ++slab) {
+            if (slabs > 1) load_slab(slab);
+#pragma unroll
+            for (int j = 0; j < ACT_CH; ++j) {
+                const int ch = slab * ACT_COLS * ACT_CH + col + ACT_COLS * j;
+                if (ch >= nch) continue;
+                const uint32_t keep = (chunk_ok(slab, j) && !bad) ? 0xFFFFFFFFu : 0u;
+                uint32_t nat[4];                               // e4m3 bytes of k = 4 dw .. 4 dw + 3, natural order
+                int part = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float y[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] = __uint_as_float(__float_as_uint(xv[j][q][i]) & keep) / scale;
+                    int v = __builtin_amdgcn_cvt_pk_fp8_f32(y[0], y[1], 0, false);
+                    v = __builtin_amdgcn_cvt_pk_fp8_f32(y[2], y[3], v, true);
+                    nat[q] = (uint32_t)v;
+                    part += (int)(__builtin_amdgcn_cvt_f32_fp8(v, 0) * 512.0f) + (int)(__builtin_amdgcn_cvt_f32_fp8(v, 1) * 512.0f)
+                          + (int)(__builtin_amdgcn_cvt_f32_fp8(v, 2) * 512.0f) + (int)(__builtin_amdgcn_cvt_f32_fp8(v, 3) * 512.0f);
+                }
+                sum8 += part;
+                // same byte order as the limbs: (0,2,4,6) then (1,3,5,7) of every group of 8
+                const uint32_t w0 = __builtin_amdgcn_perm(nat[1], nat[0], 0x06040200u), w1 = __builtin_amdgcn_perm(nat[1], nat[0], 0x07050301u);
+                const uint32_t w2 = __builtin_amdgcn_perm(nat[3], nat[2], 0x06040200u), w3 = __builtin_amdgcn_perm(nat[3], nat[2], 0x07050301u);
+                const int kb = ch >> 4, c16 = ch & 15;
+                const int ks = 2 * (c16 >> 2) + (c16 & 1), g = (c16 >> 1) & 1;
+                int8_t *dst = limbs + (((size_t)kb) * MBT + mb) * 8192 + ((ks * 64) + g * 32 + r32) * 16;
+                *reinterpret_cast<v4i *>(dst) = v4i{(int)w0, (int)w1, (int)w2, (int)w3};
+            }
+        }
+#pragma unroll
+        for (int o = ACT_ROWS; o < 64; o <<= 1) sum8 += __shfl_xor(sum8, o, 64);
+        if (lane < ACT_ROWS) s_sum8[wave][lane] = sum8;
+        __syncthreads();
+        if (tid < ACT_ROWS && tok >= 0) {
+            const long long tot = (s_sum8[0][tid] + s_sum8[1][tid]) + (s_sum8[2][tid] + s_sum8[3][tid]);
+            rowsum[tok] = __float_as_int((float)tot * 0x1p-9f);
+        }
+        return;
+    }
     const int e = act_exponent<L>(bad ? 0.0f : m);
     const float inv = bad ? 0.0f : ldexpf(1.0f, -e);           // non-finite row: limbs 0, delta NaN -> outputs NaN
     if (tid < ACT_ROWS && tok >= 0) delta[tok] = bad ? __builtin_nanf("") : ldexpf(1.0f, e);

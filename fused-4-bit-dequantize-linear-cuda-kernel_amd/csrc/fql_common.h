@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -14,6 +17,10 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // Rows of one MFMA row-block (v_mfma_i32_32x32x32_i8).  Every expert's rows start at a multiple of
 // this in the limb workspace, so a wave's A fragment is one contiguous 1 KiB.
 #define FQL_MB 32
+
+// E8M0 block scales of the scaled matrix-core instruction, one byte per lane (op_sel 0 = byte 0): 2^(v - 127)
+#define FQL_E8M0_ONE 0x7F7F7F7F
+#define FQL_E8M0_2P9 0x88888888
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
 

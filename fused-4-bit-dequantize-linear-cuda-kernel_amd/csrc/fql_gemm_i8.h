@@ -70,7 +70,14 @@ struct GemmTile {              // wave-uniform description of one BM x BN tile
 __device__ __forceinline__ void wait_lgkmcnt0() { __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14)); }
 
 
-template <int L, int WM, int WN, int NF, int DEPTH, int BDEPTH>
+// F8 (L = 1 only): the activation bytes are OCP e4m3 values (csrc/fql_act_f8.h) instead of int8 limbs and the
+// contraction runs on v_mfma_scale_f32_32x32x64_f8f6f4 -- one instruction per PAIR of 32-deep k-steps, float32
+// accumulation.  The weight operand needs no conversion: the nibble byte 0000qqqq read as e4m3 (exponent field 0
+// or 1) IS q * 2^-9, and the instruction's E8M0 block scale of the weight operand is set to 2^9, so the
+// accumulator holds sum_k q * a.  Which true k a byte slot holds is irrelevant to the matrix core as long as both
+// operands agree, so the fragment layouts of the INT8 path are used unchanged (checked on hardware:
+// tools/micro/mfma_f8_probe.hip).
+template <int L, int WM, int WN, int NF, int DEPTH, int BDEPTH, bool F8 = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     const int8_t *__restrict__ limbs, const float *__restrict__ delta,
     const int32_t *__restrict__ rowsum, const uint8_t *__restrict__ packed,
@@ -81,6 +88,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub
     using C = GemmCfg<L, WM, WN, NF, DEPTH, BDEPTH>;
     constexpr int KS = C::KS, D = C::D;
+    static_assert(!F8 || (L == 1 && D % 2 == 0), "the fp8 form has one activation byte plane and consumes k-steps in pairs");
+    using acc_t = typename std::conditional<F8, v16f, v16i>::type;
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     // ---- tiles.  Real m-tiles are counted on the device (expert counts live there).  The launch is
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     const int sA = ((cur.prow0 >> 5) + wm) * 8192;           // ... and of its activation offsets
     float *sz = szbuf + parity * 2 * C::BN;
 
-    v16i acc[L][NF];
+    acc_t acc[L][NF];
 #pragma unroll
     for (int l = 0; l < L; ++l)
 #pragma unroll
@@ -304,11 +313,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
 #pragma unroll
                 for (int j = 0; j < NF; ++j) asm volatile("" ::"v"(bfr2[b][j]));
 #else
+                if constexpr (F8) {
+                    if (b == 1) {              // steps ks-1 and ks together: 64 k per instruction
+                        const v8i a8 = {afr[(ks - 1) % D][0][0], afr[(ks - 1) % D][0][1], afr[(ks - 1) % D][0][2], afr[(ks - 1) % D][0][3],
+                                        afr[ks % D][0][0], afr[ks % D][0][1], afr[ks % D][0][2], afr[ks % D][0][3]};
 #pragma unroll
-                for (int l = 0; l < L; ++l)
+                        for (int j = 0; j < NF; ++j) {
+                            const v8i w8 = {bfr2[0][j][0], bfr2[0][j][1], bfr2[0][j][2], bfr2[0][j][3],
+                                            bfr2[1][j][0], bfr2[1][j][1], bfr2[1][j][2], bfr2[1][j][3]};
+                            acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8, a8, acc[0][j], 0, 0, 0, FQL_E8M0_2P9, 0, FQL_E8M0_ONE);
+                        }
+                    }
+                } else {
 #pragma unroll
-                    for (int j = 0; j < NF; ++j)
-                        acc[l][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bfr2[b][j], afr[ks % D][l], acc[l][j], 0, 0, 0);
+                    for (int l = 0; l < L; ++l)
+#pragma unroll
+                        for (int j = 0; j < NF; ++j)
+                            acc[l][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bfr2[b][j], afr[ks % D][l], acc[l][j], 0, 0, 0);
+                }
 #endif
 #pragma unroll
                 for (int j = 0; j < NF; ++j) {  // unpack for the next step under the MFMAs
@@ -326,10 +348,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
                 // refill the ring slot just consumed with the A fragments D steps ahead
                 const int nks = ks + D;
 #if !(defined(FQL_ABLATE) && FQL_ABLATE == 2)      // ablation 2: no A refills (timing experiment only, wrong results)
+                if constexpr (F8) {
+                    if (b == 1) {
 #pragma unroll
-                for (int l = 0; l < L; ++l)
-                    afr[ks % D][l] = __builtin_amdgcn_raw_buffer_load_b128(
-                        rsA, aoff0, sA + l * a_limb + (kt + nks / KS) * a_stage + (nks % KS) * 1024, 0);
+                        for (int s = ks - 1; s <= ks; ++s)
+                            afr[s % D][0] = __builtin_amdgcn_raw_buffer_load_b128(
+                                rsA, aoff0, sA + (kt + (s + D) / KS) * a_stage + ((s + D) % KS) * 1024, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int l = 0; l < L; ++l)
+                        afr[ks % D][l] = __builtin_amdgcn_raw_buffer_load_b128(
+                            rsA, aoff0, sA + l * a_limb + (kt + nks / KS) * a_stage + (nks % KS) * 1024, 0);
+                }
 #else
                 (void)nks;
 #endif
@@ -402,9 +433,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float tot = 0.0f;
+                    if constexpr (F8) {
+                        tot = fmaf(-z4[c], __builtin_bit_cast(float, rsi[0]), acc[0][j][4 * q + c]);
+                    } else {
 #pragma unroll
-                    for (int l = L - 1; l >= 0; --l)
-                        tot = fmaf(tot, 256.0f, fmaf(-z4[c], rs[l], (float)acc[l][j][4 * q + c]));
+                        for (int l = L - 1; l >= 0; --l)
+                            tot = fmaf(tot, 256.0f, fmaf(-z4[c], rs[l], (float)acc[l][j][4 * q + c]));
+                    }
                     o[c] = (tot * d) * s4[c];
                 }
                 store_out4(out, out_kind, (size_t)t * N, n0 + c0, N, vec, o);

@@ -5,6 +5,7 @@
 #include "../../include/fql_int4.h"
 #include "fql_common.h"
 #include "fql_act_quant.h"
+#include "fql_act_f8.h"
 #include "fql_gemm_i8.h"
 #include "fql_gemm_rows32.h"
 #include "fql_gemm_rows16.h"
@@ -27,8 +28,10 @@ inline int limbs_of(int precision)
     if (precision == FQL_PRECISION_DEFAULT) return 3;
     if (precision == FQL_PRECISION_INT8 || precision == FQL_PRECISION_FAST || precision == FQL_PRECISION_EXACT)
         return precision;
+    if (precision == FQL_PRECISION_FP8) return 1;            // one byte plane of e4m3 values
     return -1;
 }
+inline bool is_f8(int precision) { return precision == FQL_PRECISION_FP8; }
 
 struct Workspace {
     int8_t *limbs;
@@ -133,7 +136,7 @@ inline int dtype_bytes(int dt) { return dt == FQL_DTYPE_F32 ? 4 : 2; }
 template <int L>
 int launch_act_quant(const void *x, int in_dtype, const int32_t *gather, int n_src, const Workspace &w, int T, int K,
                      int Kp, int MBT, void *out, int out_dtype, int N, const int32_t *tpe, const int32_t *offs, int E,
-                     hipStream_t st, bool gated = false)
+                     hipStream_t st, bool gated = false, bool f8out = false)
 {
     // 8-row workgroups over the padded rows that can hold real rows (every expert's rows rounded up to 32), plus
     // (MoE entry point) the workgroups that zero the rows of `out` no expert covers
@@ -143,7 +146,15 @@ int launch_act_quant(const void *x, int in_dtype, const int32_t *gather, int n_s
     const bool vec = (K % 16 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
     void (*kern)(const void *, const int32_t *, int, float *, int32_t *, int8_t *, int, int, int, int, int, void *, int,
                  int, const int32_t *, const int32_t *, int);
-    if (gated) kern = vec ? act_fused_kernel<L, true, 0, true> : act_fused_kernel<L, false, 0, true>;
+    if (f8out) {
+        if constexpr (L == 1) {
+            switch (in_dtype) {
+            case FQL_DTYPE_F16: kern = vec ? act_fused_kernel<1, true, 1, false, true> : act_fused_kernel<1, false, 1, false, true>; break;
+            case FQL_DTYPE_BF16: kern = vec ? act_fused_kernel<1, true, 2, false, true> : act_fused_kernel<1, false, 2, false, true>; break;
+            default: kern = vec ? act_fused_kernel<1, true, 0, false, true> : act_fused_kernel<1, false, 0, false, true>; break;
+            }
+        } else return FQL_ERR_BAD_PRECISION;
+    } else if (gated) kern = vec ? act_fused_kernel<L, true, 0, true> : act_fused_kernel<L, false, 0, true>;
     else switch (in_dtype) {
     case FQL_DTYPE_F16: kern = vec ? act_fused_kernel<L, true, 1> : act_fused_kernel<L, false, 1>; break;
     case FQL_DTYPE_BF16: kern = vec ? act_fused_kernel<L, true, 2> : act_fused_kernel<L, false, 2>; break;
@@ -154,13 +165,13 @@ int launch_act_quant(const void *x, int in_dtype, const int32_t *gather, int n_s
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
-template <int L, int WM, int WN, int NF, int DEPTH, int BDEPTH>
+template <int L, int WM, int WN, int NF, int DEPTH, int BDEPTH, bool F8 = false>
 int launch_gemm_cfg(const Workspace &w, const uint8_t *packed, const float *scales, const float *zps,
                     void *out, int out_dtype, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp,
                     int MBT, int N, hipStream_t st)
 {
     using C = GemmCfg<L, WM, WN, NF, DEPTH, BDEPTH>;
-    auto kern = gemm_i8_kernel<L, WM, WN, NF, DEPTH, BDEPTH>;
+    auto kern = gemm_i8_kernel<L, WM, WN, NF, DEPTH, BDEPTH, F8>;
     static bool attr_set = false;           // idempotent; a race only repeats the same call
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -258,6 +269,44 @@ int launch_gemm(int cfg, const Workspace &w, const uint8_t *packed, const float 
     }
 }
 
+// fp8-activation form of the wide kernel (gemm_i8_kernel<1, ..., F8 = true>): the configurations it is built for.
+#define FQL_F8_CFG_LIST(Y)                                                                                         \
+    Y(1, 4, 2, 2, 4, 1)        /* 128 x 128 */ \
+    Y(5, 1, 8, 1, 4, 1)        /*  32 x 256 */ \
+    Y(6, 4, 1, 2, 8, 4)        /* 128 x  64, 4 waves */ \
+    Y(7, 2, 2, 1, 8, 4)        /*  64 x  64, 4 waves */ \
+    Y(8, 1, 2, 1, 8, 4)        /*  32 x  64, 2 waves */ \
+    Y(11, 2, 4, 3, 8, 2)       /*  64 x 384, full-stage activation ring, 2 weight stages */ \
+    Y(12, 4, 2, 3, 8, 2)       /* 128 x 192, full-stage activation ring, 2 weight stages */
+inline bool valid_cfg_f8(int cfg) { return cfg == 1 || cfg == 5 || cfg == 6 || cfg == 7 || cfg == 8 || cfg == 11 || cfg == 12; }
+
+int launch_gemm_f8(int cfg, const Workspace &w, const uint8_t *packed, const float *scales, const float *zps, void *out,
+                   int out_dtype, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT, int N,
+                   hipStream_t st)
+{
+    switch (cfg) {
+#define Y(id, wm, wn, nf, d, bp)                                                                                  \
+    case id:                                                                                                      \
+        return launch_gemm_cfg<1, wm, wn, nf, d, bp, true>(w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, \
+                                                           Kp, MBT, N, st);
+        FQL_F8_CFG_LIST(Y)
+#undef Y
+    default: return FQL_ERR_BAD_SHAPE;
+    }
+}
+
+// Tile choice of the fp8 form: weight-streaming bound at every shape it is meant for (one MFMA pass).
+inline int choose_cfg_f8(int E, int T, int N, bool grouped)
+{
+    const int groups = grouped ? (E > 0 ? E : 1) : 1;
+    const int m = (T + groups - 1) / groups;
+    const long long wide_tiles = (long long)groups * ((m + 127) / 128) * ((N + 255) / 256);
+    if (wide_tiles < 128 && m <= 128) return m <= 32 ? 8 : (m <= 64 ? 7 : 6);
+    if (m <= 32) return 5;
+    if (m <= 64) return 11;
+    return 12;
+}
+
 // Heuristic tile choice for the product path (MI355X: 256 CUs, one workgroup per CU).
 //   rows per group decide the tile height (32 / 64 / 128-row tiles: a short group must not pay for
 //   128 rows of MFMA work); the tile width is the one that needs the least "rounds x width" of the
@@ -301,7 +350,8 @@ inline int choose_cfg(int L, int E, int T, int K, int N, bool grouped)
 
 int run_mfma(int L, const void *x, int in_dtype, const int32_t *gather, int n_src, const uint8_t *packed,
              const float *scales, const float *zps, void *out, int out_dtype, const int32_t *tpe, const int32_t *offs,
-             int E, int T, int K, int N, void *workspace, size_t workspace_bytes, hipStream_t st, bool gated = false)
+             int E, int T, int K, int N, void *workspace, size_t workspace_bytes, hipStream_t st, bool gated = false,
+             bool f8 = false)
 {
     const int Kp = padded_k(K);
     const int MBT = row_blocks(T, E);
@@ -309,8 +359,14 @@ int run_mfma(int L, const void *x, int in_dtype, const int32_t *gather, int n_sr
     const Workspace w = carve(workspace, L, T, E, Kp);
     if (workspace_bytes < w.bytes) return FQL_ERR_WORKSPACE;
     void *zero_out = (tpe != nullptr) ? out : nullptr;
-    const int cfg = choose_cfg(L, E, T, K, N, tpe != nullptr);
     int rc;
+    if (f8) {                                                // float rows -> e4m3 with a per-row scale, one fp8 MFMA pass
+        if (gated) return FQL_ERR_BAD_PRECISION;
+        rc = launch_act_quant<1>(x, in_dtype, gather, n_src, w, T, K, Kp, MBT, zero_out, out_dtype, N, tpe, offs, E, st, false, true);
+        if (rc != FQL_OK) return rc;
+        return launch_gemm_f8(choose_cfg_f8(E, T, N, tpe != nullptr), w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, st);
+    }
+    const int cfg = choose_cfg(L, E, T, K, N, tpe != nullptr);
     if (L == 1) {
         rc = launch_act_quant<1>(x, in_dtype, gather, n_src, w, T, K, Kp, MBT, zero_out, out_dtype, N, tpe, offs, E, st, gated);
         if (rc != FQL_OK) return rc;
@@ -359,6 +415,8 @@ int launch_gemv(const float *x, const uint8_t *packed, const float *scales, cons
 
 }  // namespace
 
+static bool valid_dtype(int dt) { return dt == FQL_DTYPE_F32 || dt == FQL_DTYPE_F16 || dt == FQL_DTYPE_BF16; }
+
 extern "C" {
 
 int fql_version(void) { return FQL_VERSION; }
@@ -372,7 +430,7 @@ const char *fql_error_string(int code)
     case FQL_ERR_ODD_K: return "input_dim (K) must be even: two 4-bit weights per packed byte";
     case FQL_ERR_WORKSPACE: return "workspace is NULL, not 16-byte aligned, or smaller than *_workspace_bytes()";
     case FQL_ERR_LAUNCH: return "kernel launch failed (hipGetLastError)";
-    case FQL_ERR_BAD_PRECISION: return "precision must be FQL_PRECISION_DEFAULT, _INT8 (1), _FAST (2) or _EXACT (3)";
+    case FQL_ERR_BAD_PRECISION: return "precision must be FQL_PRECISION_DEFAULT, _INT8 (1), _FAST (2), _EXACT (3) or _FP8 (8), and is supported by this entry point";
     case FQL_ERR_DTYPE: return "element type not supported on this path (16-bit input / output exists on the MFMA path only)";
     case FQL_ERR_ALIGNMENT: return "tensor base pointer not aligned as documented";
     default: return "unknown error code";
@@ -385,7 +443,7 @@ size_t fql_linear_workspace_bytes(int B, int K, int N, int precision)
 {
     (void)N;
     const int L = limbs_of(precision);
-    if (L < 0 || B <= 4 || K <= 0 || (K % 32) != 0) return 0;
+    if (L < 0 || (B <= 4 && !is_f8(precision)) || B <= 0 || K <= 0 || (K % 32) != 0) return 0;
     Workspace w = carve(nullptr, L, B, 1, padded_k(K));
     return w.bytes;
 }
@@ -424,9 +482,10 @@ int fql_linear_fwd_f32(const float *x, const uint8_t *packed, const float *scale
         }
         return run_generic(x, packed, scales, zps, out, nullptr, nullptr, 1, B, K, N, st);
     }
+    if (is_f8(precision) && !mfma_eligible(L, B, 1, K, N, packed)) return FQL_ERR_ALIGNMENT;   // fp8 exists on the MFMA path only
     if (mfma_eligible(L, B, 1, K, N, packed))
         return run_mfma(L, x, FQL_DTYPE_F32, nullptr, 0, packed, scales, zps, out, FQL_DTYPE_F32, nullptr, nullptr, 1, B, K, N,
-                        workspace, workspace_bytes, st);
+                        workspace, workspace_bytes, st, false, is_f8(precision));
     return run_generic(x, packed, scales, zps, out, nullptr, nullptr, 1, B, K, N, st);
 }
 
@@ -449,8 +508,8 @@ static int moe_entry(const uint8_t *packed, const float *scales, const float *zp
     if (E > 65535) return FQL_ERR_BAD_SHAPE;
     if (mfma_eligible(L, T, E, K, N, packed))
         return run_mfma(L, inputs, FQL_DTYPE_F32, row_index, n_src, packed, scales, zps, out, FQL_DTYPE_F32,
-                        tokens_per_expert, input_offsets, E, T, K, N, workspace, workspace_bytes, st);
-    if (row_index != nullptr) return FQL_ERR_ALIGNMENT;     // the fused gather exists on the MFMA path only
+                        tokens_per_expert, input_offsets, E, T, K, N, workspace, workspace_bytes, st, false, is_f8(precision));
+    if (row_index != nullptr || is_f8(precision)) return FQL_ERR_ALIGNMENT;     // the fused gather / fp8 exist on the MFMA path only
     return run_generic(inputs, packed, scales, zps, out, tokens_per_expert, input_offsets, E, T, K, N, st);
 }
 
@@ -472,7 +531,6 @@ int fql_moe_gather_fwd_f32(const uint8_t *packed, const float *scales, const flo
                      N, precision, workspace, workspace_bytes, stream);
 }
 
-static bool valid_dtype(int dt) { return dt == FQL_DTYPE_F32 || dt == FQL_DTYPE_F16 || dt == FQL_DTYPE_BF16; }
 
 int fql_native_dtype_supported(int rows, int E, int K, int N, int precision, const void *packed, int grouped)
 {
@@ -498,7 +556,7 @@ int fql_linear_fwd(const void *x, int in_dtype, const uint8_t *packed, const flo
     if (!x || !packed || !scales || !zps || !out) return FQL_ERR_NULL_POINTER;
     if (B <= 4 || !mfma_eligible(L, B, 1, K, N, packed)) return FQL_ERR_DTYPE;   // 16-bit I/O exists on the MFMA path only
     return run_mfma(L, x, in_dtype, nullptr, 0, packed, scales, zps, out, out_dtype, nullptr, nullptr, 1, B, K, N,
-                    workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+                    workspace, workspace_bytes, static_cast<hipStream_t>(stream), false, is_f8(precision));
 }
 
 int fql_moe_fwd(const uint8_t *packed, const float *scales, const float *zps, const void *inputs, int in_dtype,
@@ -518,7 +576,54 @@ int fql_moe_fwd(const uint8_t *packed, const float *scales, const float *zps, co
     if (E > 65535) return FQL_ERR_BAD_SHAPE;
     if (!mfma_eligible(L, T, E, K, N, packed)) return FQL_ERR_DTYPE;
     return run_mfma(L, inputs, in_dtype, nullptr, 0, packed, scales, zps, out, out_dtype, tokens_per_expert,
-                    input_offsets, E, T, K, N, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+                    input_offsets, E, T, K, N, workspace, workspace_bytes, static_cast<hipStream_t>(stream), false, is_f8(precision));
+}
+
+// ---- rows that are already OCP e4m3 (BASELINE.json configs[4]): re-layout pre-pass + one fp8 MFMA pass
+static int f8_entry(const uint8_t *packed, const float *scales, const float *zps, const uint8_t *x8, const float *act_scales,
+                    const int32_t *tpe, const int32_t *offs, void *out, int out_dtype, int E, int T, int K, int N,
+                    void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!valid_dtype(out_dtype)) return FQL_ERR_DTYPE;
+    if (E <= 0 || T < 0 || K <= 0 || N < 0) return FQL_ERR_BAD_SHAPE;
+    if (K & 1) return FQL_ERR_ODD_K;
+    if (T == 0 || N == 0) return FQL_OK;
+    if (!packed || !scales || !zps || !x8 || !out) return FQL_ERR_NULL_POINTER;
+    if ((tpe == nullptr) != (offs == nullptr)) return FQL_ERR_NULL_POINTER;
+    if (tpe == nullptr && E != 1) return FQL_ERR_BAD_SHAPE;
+    if (E > 65535) return FQL_ERR_BAD_SHAPE;
+    if (!mfma_eligible(1, T, E, K, N, packed)) return FQL_ERR_ALIGNMENT;      // K % 32 == 0, 16-byte aligned weights
+    const int Kp = padded_k(K), MBT = row_blocks(T, E);
+    if (workspace == nullptr || !aligned16(workspace)) return FQL_ERR_WORKSPACE;
+    const Workspace w = carve(workspace, 1, T, E, Kp);
+    if (workspace_bytes < w.bytes) return FQL_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int mblocks = (tpe == nullptr) ? (T + FQL_MB - 1) / FQL_MB : (T + FQL_MB * E) / FQL_MB;
+    const int rblocks = mblocks * (FQL_MB / ACT_ROWS);
+    const int zblocks = (tpe != nullptr) ? (T + 255) / 256 : 0;
+    const int vec = ((K % 16) == 0 && (reinterpret_cast<uintptr_t>(x8) % 16) == 0) ? 1 : 0;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(act_f8_relayout_kernel, dim3(rblocks + zblocks), dim3(256), 0, st, x8, act_scales, (const int32_t *)nullptr, 0,
+                       w.delta, w.rowsum, w.limbs, T, K, Kp / FQL_KB, MBT, rblocks, out, dtype_bytes(out_dtype), N, tpe, offs, E, vec);
+    if (hipGetLastError() != hipSuccess) return FQL_ERR_LAUNCH;
+    return launch_gemm_f8(choose_cfg_f8(E, T, N, tpe != nullptr), w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, st);
+}
+
+int fql_moe_fwd_f8(const uint8_t *packed, const float *scales, const float *zps, const uint8_t *inputs_e4m3,
+                   const float *act_scales, const int32_t *tokens_per_expert, const int32_t *input_offsets, void *out,
+                   int out_dtype, int E, int T, int K, int N, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!tokens_per_expert || !input_offsets) return FQL_ERR_NULL_POINTER;
+    return f8_entry(packed, scales, zps, inputs_e4m3, act_scales, tokens_per_expert, input_offsets, out, out_dtype, E, T, K, N,
+                    workspace, workspace_bytes, stream);
+}
+
+int fql_linear_fwd_f8(const uint8_t *x_e4m3, const float *act_scales, const uint8_t *packed, const float *scales,
+                      const float *zps, void *out, int out_dtype, int B, int K, int N, void *workspace,
+                      size_t workspace_bytes, void *stream)
+{
+    return f8_entry(packed, scales, zps, x_e4m3, act_scales, nullptr, nullptr, out, out_dtype, 1, B, K, N, workspace,
+                    workspace_bytes, stream);
 }
 
 int fql_moe_gated_fwd_f32(const uint8_t *packed, const float *scales, const float *zps, const float *gate_up,
@@ -526,7 +631,7 @@ int fql_moe_gated_fwd_f32(const uint8_t *packed, const float *scales, const floa
                           int K, int N, int precision, void *workspace, size_t workspace_bytes, void *stream)
 {
     const int L = limbs_of(precision);
-    if (L < 0) return FQL_ERR_BAD_PRECISION;
+    if (L < 0 || is_f8(precision)) return FQL_ERR_BAD_PRECISION;
     if (E <= 0 || T < 0 || K <= 0 || N < 0) return FQL_ERR_BAD_SHAPE;
     if (K & 1) return FQL_ERR_ODD_K;
     if (T == 0 || N == 0) return FQL_OK;
@@ -629,7 +734,7 @@ int fql_act_quant_f32(const float *x, int8_t *limbs, float *delta, int32_t *rows
     w.limbs = limbs; w.delta = delta; w.rowsum = rowsum; w.bytes = 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int Kp = padded_k(K), MBT = row_blocks(T, E);
-    if (L == 1) return launch_act_quant<1>(x, FQL_DTYPE_F32, nullptr, 0, w, T, K, Kp, MBT, nullptr, FQL_DTYPE_F32, 0, tokens_per_expert, input_offsets, E, st);
+    if (L == 1) return launch_act_quant<1>(x, FQL_DTYPE_F32, nullptr, 0, w, T, K, Kp, MBT, nullptr, FQL_DTYPE_F32, 0, tokens_per_expert, input_offsets, E, st, false, is_f8(precision));
     if (L == 2) return launch_act_quant<2>(x, FQL_DTYPE_F32, nullptr, 0, w, T, K, Kp, MBT, nullptr, FQL_DTYPE_F32, 0, tokens_per_expert, input_offsets, E, st);
     return launch_act_quant<3>(x, FQL_DTYPE_F32, nullptr, 0, w, T, K, Kp, MBT, nullptr, FQL_DTYPE_F32, 0, tokens_per_expert, input_offsets, E, st);
 }
@@ -674,8 +779,13 @@ static int gemm_i8_entry(int cfg, const int8_t *limbs, const float *delta, const
     if (tokens_per_expert == nullptr && E != 1) return FQL_ERR_BAD_SHAPE;
     if ((K % 32) != 0 || !aligned16(packed) || !aligned16(limbs)) return FQL_ERR_ALIGNMENT;
     if (!mfma_addressable(L, T, E, K, N)) return FQL_ERR_BAD_SHAPE;
-    if (cfg < 0) cfg = choose_cfg(L, E, T, K, N, tokens_per_expert != nullptr);
-    if (!valid_cfg(cfg)) return FQL_ERR_BAD_SHAPE;
+    if (is_f8(precision)) {
+        if (cfg < 0) cfg = choose_cfg_f8(E, T, N, tokens_per_expert != nullptr);
+        if (!valid_cfg_f8(cfg)) return FQL_ERR_BAD_SHAPE;
+    } else {
+        if (cfg < 0) cfg = choose_cfg(L, E, T, K, N, tokens_per_expert != nullptr);
+        if (!valid_cfg(cfg)) return FQL_ERR_BAD_SHAPE;
+    }
     Workspace w;
     w.limbs = const_cast<int8_t *>(limbs);
     w.delta = const_cast<float *>(delta);
@@ -683,6 +793,8 @@ static int gemm_i8_entry(int cfg, const int8_t *limbs, const float *delta, const
     w.bytes = 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int Kp = padded_k(K), MBT = row_blocks(T, E);
+    if (is_f8(precision))
+        return launch_gemm_f8(cfg, w, packed, scales, zps, out, FQL_DTYPE_F32, tokens_per_expert, input_offsets, E, T, K, Kp, MBT, N, st);
     if (L == 1)
         return launch_gemm<1>(cfg, w, packed, scales, zps, out, FQL_DTYPE_F32, tokens_per_expert, input_offsets, E, T, K, Kp, MBT, N, st);
     if (L == 2)
@@ -705,7 +817,7 @@ FQL_API int fql_tune_gemm_i8_f32(int cfg, const int8_t *limbs, const float *delt
                                  const int32_t *tokens_per_expert, const int32_t *input_offsets, float *out, int E,
                                  int T, int K, int N, int precision, void *stream)
 {
-    if (!valid_cfg(cfg)) return FQL_ERR_BAD_SHAPE;
+    if (!(precision == FQL_PRECISION_FP8 ? valid_cfg_f8(cfg) : valid_cfg(cfg))) return FQL_ERR_BAD_SHAPE;
     return gemm_i8_entry(cfg, limbs, delta, rowsum, packed, scales, zps, tokens_per_expert, input_offsets, out, E, T,
                          K, N, precision, stream);
 }

@@ -14,14 +14,20 @@ import torch
 from . import _native
 
 _PRECISIONS = {"default": _native.PRECISION_DEFAULT, "exact": _native.PRECISION_EXACT,
-               "fast": _native.PRECISION_FAST, "int8": _native.PRECISION_INT8, 0: 0, 1: 1, 2: 2, 3: 3}
+               "fast": _native.PRECISION_FAST, "int8": _native.PRECISION_INT8, "fp8": _native.PRECISION_FP8,
+               0: 0, 1: 1, 2: 2, 3: 3, 8: 8}
+
+
+def _planes(prec):
+    """Byte planes of the activation workspace: 3 / 2 / 1 int8 limbs, or one plane of e4m3 values."""
+    return {0: 3, 8: 1}.get(prec, prec)
 
 
 def _precision(p):
     try:
         return _PRECISIONS[p]
     except KeyError:
-        raise ValueError(f"precision must be 'default', 'exact', 'fast' or 'int8', got {p!r}") from None
+        raise ValueError(f"precision must be 'default', 'exact', 'fast', 'int8' or 'fp8', got {p!r}") from None
 
 
 def _stream_ptr(device):
@@ -418,7 +424,7 @@ def act_quant(x, precision="default", tokens_per_expert=None, input_offsets=None
     x = x.contiguous()
     T, K = x.shape
     prec = _precision(precision)
-    nl = 3 if prec == 0 else prec
+    nl = _planes(prec)
     grouped = tokens_per_expert is not None
     E = tokens_per_expert.numel() if grouped else 1
     L = _native.lib()
@@ -448,7 +454,7 @@ def gemm_i8(limbs, delta, rowsum, packed_weights, scales, zero_points, tokens_pe
     N, K2 = packed_weights.shape[-2:]
     K = 2 * K2
     prec = _precision(precision)
-    if (3 if prec == 0 else prec) != rowsum.shape[0]:
+    if _planes(prec) != rowsum.shape[0]:
         raise RuntimeError("limb count does not match precision")
     if limbs.numel() < _native.lib().fql_act_limb_bytes(T, E, K, prec):
         raise RuntimeError("limbs were not produced for this T, E, K")
@@ -463,4 +469,108 @@ def gemm_i8(limbs, delta, rowsum, packed_weights, scales, zero_points, tokens_pe
                                            packed_weights.data_ptr(), scales.data_ptr(), zero_points.data_ptr(),
                                            tpe_ptr, off_ptr, out.data_ptr(), E, T, K, N, prec, _stream_ptr(dev))
     _native.check(rc, "fql_gemm_i8_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ fp8 activations
+def _as_e4m3_bytes(t, name):
+    if t.dtype == torch.uint8:
+        return t
+    if t.dtype == getattr(torch, "float8_e4m3fn", None):
+        return t.view(torch.uint8)
+    raise RuntimeError(f"{name} must be torch.float8_e4m3fn (or its uint8 bytes)")
+
+
+def quantize_activations_fp8(x):
+    """Per-row OCP e4m3 quantisation with torch ops (for callers that want to hold fp8 activations themselves):
+    ``scale[t] = max|x[t]| / 448`` (1 for an all-zero row), ``x8 = (x / scale).to(torch.float8_e4m3fn)``.
+    ``precision="fp8"`` on the float entry points does the same inside the fused pre-pass."""
+    x = x.float()
+    amax = x.abs().amax(dim=1)
+    # tensor / tensor: a true float32 division (torch turns `/ 448.0` into a multiplication by the reciprocal, one ulp off)
+    scale = torch.where(amax == 0, torch.ones_like(amax), amax / torch.full_like(amax, 448.0))
+    return (x / scale[:, None]).to(torch.float8_e4m3fn), scale
+
+
+def moe_forward_fp8(packed_weights, scales, zero_points, inputs_e4m3, act_scales, tokens_per_expert, input_offsets,
+                    out_dtype=torch.float32):
+    """Grouped per-expert INT4 GEMM over rows that are already fp8: ``inputs_e4m3`` [T, K] torch.float8_e4m3fn
+    (or its uint8 bytes), ``act_scales`` [T] float32 or None.  One fp8 MFMA pass, float32 accumulation
+    (BASELINE.json configs[4]).  Returns [T, N] in ``out_dtype``; rows no expert covers are zero."""
+    x8 = _as_e4m3_bytes(inputs_e4m3, "inputs_e4m3")
+    for name, t in (("packed_weights", packed_weights), ("scales", scales), ("zero_points", zero_points), ("inputs_e4m3", x8),
+                    ("tokens_per_expert", tokens_per_expert), ("input_offsets", input_offsets)):
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} must be a CUDA tensor")
+    if packed_weights.dtype != torch.uint8 or packed_weights.dim() != 3 or x8.dim() != 2:
+        raise RuntimeError("packed_weights must be uint8 [num_experts, ffn_dim, hidden_dim/2] and inputs [total_tokens, hidden_dim]")
+    if out_dtype not in _DTYPES:
+        raise RuntimeError("outputs must be float32, float16 or bfloat16")
+    E, N, packed_dim = packed_weights.shape
+    T, K = x8.shape
+    if K % 32 != 0 or packed_dim != K // 2:
+        raise RuntimeError("the fp8 path needs hidden_dim % 32 == 0 and packed_weights dim 2 == hidden_dim / 2")
+    if tuple(scales.shape) != (E, N) or tuple(zero_points.shape) != (E, N) or scales.dtype != torch.float32 \
+            or zero_points.dtype != torch.float32:
+        raise RuntimeError("scales and zero_points must be float32 [num_experts, ffn_dim]")
+    if tokens_per_expert.numel() != E or input_offsets.numel() != E:
+        raise RuntimeError("tokens_per_expert and input_offsets must have num_experts elements")
+    dev = x8.device
+    if any(t.device != dev for t in (packed_weights, scales, zero_points)):
+        raise RuntimeError("all tensors must be on the same device")
+    if act_scales is not None:
+        if act_scales.numel() != T:
+            raise RuntimeError("act_scales must have one element per row")
+        act_scales = act_scales.to(device=dev, dtype=torch.float32).contiguous()
+    x8 = x8.contiguous()
+    tpe = tokens_per_expert.to(device=dev, dtype=torch.int32).contiguous()
+    offs = input_offsets.to(device=dev, dtype=torch.int32).contiguous()
+    L = _native.lib()
+    out = torch.empty((T, N), dtype=out_dtype, device=dev)
+    with torch.cuda.device(dev):
+        ws, ws_ptr = _workspace(L.fql_moe_workspace_bytes(E, T, K, N, _native.PRECISION_FP8), dev)
+        rc = L.fql_moe_fwd_f8(packed_weights.contiguous().data_ptr(), scales.contiguous().data_ptr(),
+                              zero_points.contiguous().data_ptr(), x8.data_ptr(),
+                              None if act_scales is None else act_scales.data_ptr(), tpe.data_ptr(), offs.data_ptr(),
+                              out.data_ptr(), _DTYPES[out_dtype], E, T, K, N, ws_ptr, 0 if ws is None else ws.numel(),
+                              _stream_ptr(dev))
+    _native.check(rc, "fql_moe_fwd_f8")
+    return out
+
+
+def linear_forward_fp8(x_e4m3, act_scales, packed_weights, scales, zero_points, out_dtype=torch.float32):
+    """Fused 4-bit dequantize + linear over fp8 rows: ``x_e4m3`` [B, K] torch.float8_e4m3fn (or uint8 bytes),
+    ``act_scales`` [B] float32 or None -> [B, N] in ``out_dtype``."""
+    x8 = _as_e4m3_bytes(x_e4m3, "x_e4m3")
+    if not x8.is_cuda or not packed_weights.is_cuda:
+        raise RuntimeError("x_e4m3 and packed_weights must be CUDA tensors")
+    if x8.dim() != 2 or packed_weights.dim() != 2 or packed_weights.dtype != torch.uint8:
+        raise RuntimeError("x_e4m3 must be [B, K] and packed_weights uint8 [N, K/2]")
+    if out_dtype not in _DTYPES:
+        raise RuntimeError("outputs must be float32, float16 or bfloat16")
+    B, K = x8.shape
+    N, packed_dim = packed_weights.shape
+    if K % 32 != 0 or packed_dim != K // 2:
+        raise RuntimeError("the fp8 path needs input_dim % 32 == 0 and packed_weights dim 1 == input_dim / 2")
+    if scales.numel() != N or zero_points.numel() != N or scales.dtype != torch.float32 or zero_points.dtype != torch.float32:
+        raise RuntimeError("scales and zero_points must be float32 with output_dim elements")
+    dev = x8.device
+    if any(t.device != dev for t in (packed_weights, scales, zero_points)):
+        raise RuntimeError("all tensors must be on the same device")
+    if act_scales is not None:
+        if act_scales.numel() != B:
+            raise RuntimeError("act_scales must have one element per row")
+        act_scales = act_scales.to(device=dev, dtype=torch.float32).contiguous()
+    x8 = x8.contiguous()
+    L = _native.lib()
+    out = torch.empty((B, N), dtype=out_dtype, device=dev)
+    if B == 0:
+        return out
+    with torch.cuda.device(dev):
+        ws, ws_ptr = _workspace(L.fql_linear_workspace_bytes(B, K, N, _native.PRECISION_FP8), dev)
+        rc = L.fql_linear_fwd_f8(x8.data_ptr(), None if act_scales is None else act_scales.data_ptr(),
+                                 packed_weights.contiguous().data_ptr(), scales.contiguous().data_ptr(),
+                                 zero_points.contiguous().data_ptr(), out.data_ptr(), _DTYPES[out_dtype], B, K, N,
+                                 ws_ptr, 0 if ws is None else ws.numel(), _stream_ptr(dev))
+    _native.check(rc, "fql_linear_fwd_f8")
     return out

@@ -72,6 +72,13 @@ extern "C" {
 #define FQL_PRECISION_INT8 1
 #define FQL_PRECISION_FAST 2
 #define FQL_PRECISION_EXACT 3
+/*   FQL_PRECISION_FP8   : activations rounded to OCP e4m3 (4-bit significand) with one float32 scale per row
+ *                         (max|x| / 448), ONE pass of the block-scaled fp8 matrix-core instruction
+ *                         (v_mfma_scale_f32_32x32x64_f8f6f4, float32 accumulation) -- the "fp8 activations + INT4
+ *                         weights" configuration of BASELINE.json configs[4].  ~2.7e-2 relative error on randn
+ *                         activations (the format's, not the kernel's): outside the 1e-3 parity claim.  MFMA path
+ *                         only (K % 32 == 0, 16-byte aligned weights, more than 4 rows for the linear op). */
+#define FQL_PRECISION_FP8 8
 
 /* Element types of activations and outputs for the dtype-generic entry points (fql_linear_fwd / fql_moe_fwd).
  * 16-bit inputs are widened exactly; outputs are rounded to nearest even from the float32 result, i.e. the
@@ -134,6 +141,29 @@ FQL_API int fql_moe_gather_fwd_f32(const uint8_t *packed, const float *scales, c
                                    const int32_t *tokens_per_expert, const int32_t *input_offsets,
                                    float *out, int E, int T, int K, int N, int precision,
                                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Activations that are ALREADY fp8 (OCP e4m3fn bytes, e.g. the output of an upstream fp8 kernel or of
+ * torch's .to(torch.float8_e4m3fn)), with an optional float32 scale per row:
+ *
+ *   out[t][n] = act_scales[t] * scale[e][n] * sum_k (q[e][n][k] - zp[e][n]) * e4m3(inputs[t][k])
+ *
+ *   inputs_e4m3 [T][K] uint8;  act_scales [T] float32 or NULL (= 1);  out [T][N] of out_dtype (FQL_DTYPE_*)
+ * One pass of the block-scaled fp8 matrix-core instruction, float32 accumulation; the 4-bit weights are exact in
+ * e4m3.  An e4m3 NaN makes its whole output row NaN.  Not in the reference (FP8 is listed as future work,
+ * README.md:228); the shape is BASELINE.json configs[4].  MFMA path only: K % 32 == 0 and 16-byte aligned
+ * `packed`, otherwise FQL_ERR_ALIGNMENT.  Workspace: fql_moe_workspace_bytes(E, T, K, N, FQL_PRECISION_FP8)
+ * (fql_linear_workspace_bytes(B, ...) for the linear form, which takes any B >= 1).
+ * ------------------------------------------------------------------------------------- */
+FQL_API int fql_moe_fwd_f8(const uint8_t *packed, const float *scales, const float *zps,
+                           const uint8_t *inputs_e4m3, const float *act_scales,
+                           const int32_t *tokens_per_expert, const int32_t *input_offsets, void *out,
+                           int out_dtype, int E, int T, int K, int N, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
+FQL_API int fql_linear_fwd_f8(const uint8_t *x_e4m3, const float *act_scales, const uint8_t *packed,
+                              const float *scales, const float *zps, void *out, int out_dtype, int B, int K,
+                              int N, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Format helpers on the device (same unpack code path as the GEMM kernels; bit-exact).

@@ -234,3 +234,71 @@ def gated_ffn_grouped(gate_up_q, down_q, x, counts, offsets):
         h = (g / (1.0 + np.exp(-g))) * u
         out[o:o + c] = h @ wd.T
     return out
+
+
+# --------------------------------------------------------------------------------------
+# fp8 (OCP e4m3fn) activations -- BASELINE.json configs[4].  NOT in the reference: it lists FP8 as
+# future work only (README.md:228), so there is no reference vector to pin this to ("parity unpinned"
+# by the reference).  The FORMAT is pinned instead: tests/test_oracle_golden.py checks the table and
+# the rounding below against torch's own float8_e4m3fn casts, and the arithmetic is the same
+# dequantize-then-matmul (python/quantize.py:176-202) applied to the decoded activations in float64.
+# --------------------------------------------------------------------------------------
+def e4m3_table():
+    """All 256 OCP e4m3fn values: 1 sign, 4 exponent (bias 7), 3 mantissa bits; no infinities;
+    S.1111.111 is NaN; exponent field 0 is subnormal (m * 2^-9)."""
+    b = np.arange(256, dtype=np.int64)
+    e = (b >> 3) & 15
+    m = b & 7
+    mag = np.where(e == 0, m * 2.0 ** -9, (1.0 + m / 8.0) * 2.0 ** (e - 7.0))
+    mag = np.where((e == 15) & (m == 7), np.nan, mag)
+    return np.where(b >= 128, -mag, mag).astype(F32)
+
+
+def e4m3_decode(xbytes):
+    return e4m3_table()[np.asarray(xbytes, dtype=np.uint8)]
+
+
+def e4m3_encode(x):
+    """float32 -> e4m3fn byte, round to nearest, ties to even mantissa; magnitudes that round above 448 (> 464)
+    and NaN become NaN (0x7F | sign), as torch's cast does."""
+    x = np.asarray(x, dtype=F32)
+    tab = e4m3_table()[:127].astype(np.float64)            # the 127 finite non-negative values, ascending (0x00..0x7E)
+    a = np.abs(x).astype(np.float64)
+    hi = np.clip(np.searchsorted(tab, a, side="left"), 1, 126)
+    lo = hi - 1
+    dlo, dhi = a - tab[lo], tab[hi] - a
+    pick_hi = (dhi < dlo) | ((dhi == dlo) & ((hi & 1) == 0))
+    code = np.where(pick_hi, hi, lo).astype(np.uint8)
+    code = np.where(a > 464.0, 0x7F, code)                  # past the midpoint between 448 and the absent 480 (the tie goes to 448)
+    code = np.where(np.isnan(x), 0x7F, code)
+    return (code | (np.signbit(x).astype(np.uint8) << 7)).astype(np.uint8)
+
+
+def quantize_activations_fp8(x):
+    """Per-row e4m3 quantisation of the library's FQL_PRECISION_FP8 mode: scale[t] = max|x[t]| / 448 in float32
+    (1 for an all-zero row), byte = e4m3(x / scale) with a float32 division."""
+    x = np.ascontiguousarray(np.asarray(x, dtype=F32))
+    amax = np.abs(x).max(axis=1)
+    scale = np.where(amax == 0, F32(1.0), amax / F32(448.0)).astype(F32)
+    return e4m3_encode((x / scale[:, None]).astype(F32)), scale
+
+
+def reference_linear_fp8(xbytes, act_scale, packed, scales, zero_points):
+    """out = (act_scale * e4m3(x)) @ dequantize_weights(...).T, accumulated in float64."""
+    a = e4m3_decode(xbytes).astype(np.float64)
+    if act_scale is not None:
+        a = a * np.asarray(act_scale, dtype=np.float64)[:, None]
+    w = dequantize_weights(packed, scales, zero_points).astype(np.float64)
+    return a @ w.T
+
+
+def reference_moe_grouped_fp8(xbytes, act_scale, packed, scales, zero_points, tokens_per_expert, input_offsets):
+    T = np.asarray(xbytes).shape[0]
+    N = np.asarray(packed).shape[1]
+    out = np.zeros((T, N), dtype=np.float64)
+    for e, (c, o) in enumerate(zip(np.asarray(tokens_per_expert), np.asarray(input_offsets))):
+        lo, hi = max(int(o), 0), min(int(o) + int(c), T)
+        if hi > lo:
+            sc = None if act_scale is None else np.asarray(act_scale)[lo:hi]
+            out[lo:hi] = reference_linear_fp8(np.asarray(xbytes)[lo:hi], sc, packed[e], scales[e], zero_points[e])
+    return out

@@ -143,3 +143,29 @@ def test_c_unpack_matches_python():
     rng = np.random.default_rng(0)
     p = rng.integers(0, 256, size=(7, 33), dtype=np.uint8)
     assert np.array_equal(C.unpack(p), O.unpack_nibbles(p))
+
+
+def test_e4m3_format_is_pinned_to_torch():
+    """fp8 activations are not in the reference (README.md:228), so the oracle's e4m3 table and rounding are pinned to
+    torch's float8_e4m3fn casts instead: all 256 codes, and round-to-nearest-even on values that include every exact
+    midpoint, the subnormals, the saturation edge (448 / 464) and signed zeros."""
+    import torch
+    tab = O.e4m3_table()
+    tt = torch.arange(256, dtype=torch.uint8).view(torch.float8_e4m3fn).float().numpy()
+    assert np.array_equal(np.isnan(tab), np.isnan(tt))
+    assert np.array_equal(tab[~np.isnan(tab)], tt[~np.isnan(tt)])
+    rng = np.random.default_rng(0)
+    fin = tab[:127]
+    x = np.concatenate([rng.standard_normal(20000).astype(np.float32) * s for s in (1e-3, 0.01, 1, 30, 200)]
+                       + [fin, -fin, (fin[:-1] + fin[1:]) / 2, np.array([448, 460, 463.9, 464, -464, 1e-9, -0.0, 0.0], np.float32)]).astype(np.float32)
+    enc = O.e4m3_encode(x)
+    tenc = torch.from_numpy(x).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    assert np.array_equal(enc, tenc)
+    assert np.array_equal(O.e4m3_decode(enc[:1000]), torch.from_numpy(x[:1000]).to(torch.float8_e4m3fn).float().numpy())
+    # the library's per-row quantisation rule == the torch-side helper a caller would use
+    xr = rng.standard_normal((7, 96)).astype(np.float32)
+    b, sc = O.quantize_activations_fp8(xr)
+    t = torch.from_numpy(xr)
+    amax = t.abs().amax(dim=1)
+    assert np.array_equal(sc, (amax / 448.0).numpy())
+    assert np.array_equal(b, (t / (amax / 448.0)[:, None]).to(torch.float8_e4m3fn).view(torch.uint8).numpy())
