@@ -43,7 +43,8 @@ _SYMBOLS = {
     "fql_act_padded_k": (ctypes.c_int, [ctypes.c_int]),
     "fql_act_limb_bytes": (ctypes.c_size_t, [ctypes.c_int] * 4),
     "fql_act_quant_f32": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
-    "fql_gemm_i8_f32": (ctypes.c_int, [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    "fql_gemm_i8_f32": (ctypes.c_int, [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "fql_gemm_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "fql_moe_gated_fwd_f32": (ctypes.c_int, [ctypes.c_void_p] * 7 + [ctypes.c_int] * 5
                               + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "fql_route_plan_i32": (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 5),

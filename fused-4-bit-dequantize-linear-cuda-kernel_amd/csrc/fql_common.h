@@ -22,6 +22,10 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define FQL_E8M0_ONE 0x7F7F7F7F
 #define FQL_E8M0_2P9 0x88888888
 
+#ifndef FQL_RES_ENABLED
+#define FQL_RES_ENABLED 1      // residual pass of heavy-tailed rows in the GEMM kernels (0: A/B timing builds only)
+#endif
+
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
 
 // Nibble unpack shared by every kernel (reference: python/quantize.py:152-163,

@@ -63,9 +63,40 @@ __device__ unsigned long long fql_trace_wide[8 * 64];
 #define FQL_WIDE_W_AUX 0       // cache policy of the wide kernel's weight loads (experiment hook; 2 = nt)
 #endif
 
-struct GemmTile {              // wave-uniform description of one BM x BN tile
+struct GemmTile {              // wave-uniform description of one visit of a BM x BN tile
     int e, row0, prow0, rows_valid, nt, ok;
+    int rp;                    // this visit is the RESIDUAL pass of a tile with heavy-tailed rows (its main pass follows)
+    int ad;                    // this visit is the main pass that follows a residual pass: add the parked partial results
 };
+
+// Heavy-tailed rows (csrc/fql_act_quant.h, pass 3): rows whose 8L-1 fixed-point bits would not carry the stated
+// precision get a second limb set for the rounding residual, stored behind the first one -- limbs2 = limbs + L planes,
+// delta2 = delta + T (0 for rows without one), rowsum2 = rowsum + L*T.  A tile with such a row is visited twice by
+// its workgroup: the residual pass parks float32 partial results delta2 * scale * (...) in a workgroup-private
+// scratch slot, the main pass that follows adds them (rows with delta2 == 0 skip the add, so they are bit-identical
+// to a tile without the residual pass: a row's result never depends on which other rows share its tile).
+// The probe is split so that its L2 round trip hides under other work: `issue` right after the tile is known (two
+// unconditional 4-byte loads per lane), `eval` (a ballot) where the answer is first needed.
+struct ResidualProbe { int v0, v1; };
+__device__ __forceinline__ ResidualProbe residual_probe_issue(const float *delta, int T, const GemmTile &tp, int bm, int lane,
+                                                              bool enable)
+{
+    // always issued (a load under a branch costs hipcc's counted waits); disabled = out-of-bounds offsets = zeros
+    const __amdgpu_buffer_rsrc_t rsD2 = __builtin_amdgcn_make_buffer_rsrc((void *)(delta + T), 0, T * 4, 0x00020000);
+    const bool on = enable && tp.ok;
+    ResidualProbe p;
+    p.v0 = __builtin_amdgcn_raw_buffer_load_b32(rsD2, (on && lane < tp.rows_valid) ? (tp.row0 + lane) * 4 : 0x7fff0000, 0, 0);
+    p.v1 = __builtin_amdgcn_raw_buffer_load_b32(rsD2, (on && bm > 64 && lane + 64 < tp.rows_valid) ? (tp.row0 + lane + 64) * 4 : 0x7fff0000, 0, 0);
+    return p;
+}
+__device__ __forceinline__ int residual_probe_eval(const ResidualProbe &p)
+{
+    return __builtin_amdgcn_readfirstlane((__ballot(((p.v0 | p.v1) & 0x7fffffff) != 0) != 0ull) ? 1 : 0);
+}
+__device__ __forceinline__ int tile_has_residual(const float *delta, int T, const GemmTile &tp, int bm, int lane)
+{
+    return residual_probe_eval(residual_probe_issue(delta, T, tp, bm, lane, true));
+}
 
 __device__ __forceinline__ void wait_lgkmcnt0() { __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14)); }
 
@@ -83,11 +114,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     const int32_t *__restrict__ rowsum, const uint8_t *__restrict__ packed,
     const float *__restrict__ scales, const float *__restrict__ zps, void *__restrict__ out, int out_kind,
     const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
-    int E, int T, int K, int Kp, int MBT, int N, int n_tiles, int m_slots)
+    int E, int T, int K, int Kp, int MBT, int N, int n_tiles, int m_slots, float *__restrict__ res_scratch)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub
     using C = GemmCfg<L, WM, WN, NF, DEPTH, BDEPTH>;
     constexpr int KS = C::KS, D = C::D;
+    constexpr bool RES = FQL_RES_ENABLED && (L >= 2) && !F8;                    // residual limb set for heavy-tailed rows (see GemmTile)
     static_assert(!F8 || (L == 1 && D % 2 == 0), "the fp8 form has one activation byte plane and consumes k-steps in pairs");
     using acc_t = typename std::conditional<F8, v16f, v16i>::type;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -116,7 +148,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     n_real = __builtin_amdgcn_readfirstlane(n_real);
 
     auto tile_params = [&](int vb) -> GemmTile {             // wave-uniform
-        GemmTile tp = {0, 0, 0, 0, 0, 0};
+        GemmTile tp = {0, 0, 0, 0, 0, 0, 0, 0};
         if (vb >= n_real) return tp;
         const int tile = xcd_remap(vb, n_real);
         const int ms = tile / n_tiles;
@@ -152,6 +184,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
         tp.ok = __builtin_amdgcn_readfirstlane(tp.ok);
         return tp;
     };
+    static_assert(C::BM <= 128, "the residual probe covers two 64-row halves");
 
     // ---- everything per-lane is tile independent; the tile enters through scalar offsets and descriptors
     constexpr int OOB = 0x7fff0000;                          // a buffer offset past every descriptor: reads zero
@@ -159,7 +192,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     const int KB = Kp / FQL_KB, KT = KB;                     // weight stages (K padded to 256 by the pre-pass)
     const size_t wbytes = (size_t)N * (size_t)(K >> 1);
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)limbs, 0, (int)((size_t)L * KB * MBT * 8192), 0x00020000);
+        (void *)limbs, 0, (int)((size_t)(RES ? 2 : 1) * L * KB * MBT * 8192), 0x00020000);
     const int a_stage = MBT * 8192;                          // bytes between consecutive kb of one limb
     // A operand: limbs[l][kb][mb][ks][lane][16 B]
     // (one base register per address family; the fragment / piece / limb index goes into the scalar offset or the
@@ -212,18 +245,25 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
 
   int ev = 0;
   GemmTile cur = tile_params(blockIdx.x);
-  issue_prologue(cur);
+  if constexpr (RES) {
+      const ResidualProbe pb = residual_probe_issue(delta, T, cur, C::BM, lane, res_scratch != nullptr);
+      issue_prologue(cur);
+      cur.rp = residual_probe_eval(pb);
+  } else {
+      issue_prologue(cur);
+  }
   int parity = 0;
-  for (int vb = blockIdx.x; vb < n_real; vb += gridDim.x, parity ^= 1) {
+  for (int vb = blockIdx.x; vb < n_real; parity ^= 1) {      // one iteration per VISIT (tile, pass); vb advances below
     FQL_WSTAMP(ev++, 1);                                     // tile start, constant 100 MHz clock
     FQL_WSTAMP(ev++, 0);                                     // tile start, shader clock
     const int e = cur.e, row0 = cur.row0, rows_valid = cur.rows_valid;
     const int n0 = cur.nt * C::BN;
+    const bool rpass = RES && cur.rp != 0;                   // residual pass: second limb set, partials to the scratch slot
     const bool active = cur.ok && wm * FQL_MB < rows_valid; // waves past the expert's last row only help stage weights
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(packed + (size_t)e * wbytes), 0, (int)wbytes, 0x00020000);
     const int sB = n0 * (K >> 1);                            // scalar part of this tile's weight offsets
-    const int sA = ((cur.prow0 >> 5) + wm) * 8192;           // ... and of its activation offsets
+    const int sA = ((cur.prow0 >> 5) + wm) * 8192 + (rpass ? L * a_limb : 0);   // ... and of its activation offsets
     float *sz = szbuf + parity * 2 * C::BN;
 
     acc_t acc[L][NF];
@@ -396,8 +436,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
    }   // cur.ok
 
     FQL_WSTAMP(ev++, 0);                                     // K loop done
-    // the next tile (its expert-table loads are short and nothing slow is ahead of them in the load queue)
-    const GemmTile nxt = tile_params(vb + gridDim.x);
+    // the next visit: the main pass of this tile after its residual pass, else the next tile (its expert-table
+    // loads are short and nothing slow is ahead of them in the load queue)
+    GemmTile nxt;
+    ResidualProbe pb = {0, 0};
+    if (rpass) { nxt = cur; nxt.rp = 0; nxt.ad = 1; }
+    else { vb += gridDim.x; nxt = tile_params(vb); }
+    if constexpr (RES) pb = residual_probe_issue(delta, T, nxt, C::BM, lane, res_scratch != nullptr && !rpass);   // evaluated after the epilogue
     // ---- epilogue: fold zero-point, combine limbs, scale.  The weights are the MFMA's A operand (rows = n)
     //      and the activations its B operand (cols = t), so in the 32x32 C/D layout
     //      (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) every lane owns ONE output
@@ -408,20 +453,30 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     const int rl = wm * FQL_MB + l31;
     const bool row_ok = active && rl < rows_valid;
     const int t = row_ok ? row0 + rl : 0;
-    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)delta, 0, T * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)rowsum, 0, L * T * 4, 0x00020000);
-    const float d = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, t * 4, 0, 0));
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)delta, 0, (RES ? 2 : 1) * T * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)rowsum, 0, (RES ? 2 : 1) * L * T * 4, 0x00020000);
+    const int tsel = rpass ? T : 0;                          // second set of per-row values in the residual pass
+    const float d = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, (tsel + t) * 4, 0, 0));
     int rsi[L];
 #pragma unroll
-    for (int l = 0; l < L; ++l) rsi[l] = __builtin_amdgcn_raw_buffer_load_b32(rsR, (l * T + t) * 4, 0, 0);
+    for (int l = 0; l < L; ++l) rsi[l] = __builtin_amdgcn_raw_buffer_load_b32(rsR, (L * tsel + l * T + t) * 4, 0, 0);
+    // main pass after a residual pass: does THIS row have a residual (delta2 != 0)?
+    const int d2bits = RES ? __builtin_amdgcn_raw_buffer_load_b32(rsD, (T + t) * 4, 0, 0) : 0;   // unconditional load
+    const bool addp = RES && (d2bits & 0x7fffffff) != 0;
     __builtin_amdgcn_sched_barrier(0);
     issue_prologue(nxt);
     __builtin_amdgcn_sched_barrier(0);
-    if (row_ok) {
+    // MODE 0: plain tile (the hot path: straight-line code, nothing of the residual machinery in it);
+    // MODE 1: residual pass -- park the float32 results in this lane's scratch slot (workgroup-private; read back by
+    //         the same lane in the next visit);  MODE 2: main pass after a residual pass -- add the parked values.
+    auto epilogue = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
         float rs[L];
 #pragma unroll
         for (int l = 0; l < L; ++l) rs[l] = (float)rsi[l];
         const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & (out_kind == 0 ? 15 : 7)) == 0);
+        float *slot0 = (MODE == 0) ? nullptr
+                                   : res_scratch + ((size_t)blockIdx.x * C::NW + wave) * (NF * 1024) + lane * 4;
 #pragma unroll
         for (int j = 0; j < NF; ++j)
 #pragma unroll
@@ -442,9 +497,26 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
                     }
                     o[c] = (tot * d) * s4[c];
                 }
-                store_out4(out, out_kind, (size_t)t * N, n0 + c0, N, vec, o);
+                if constexpr (MODE == 1) {
+                    *reinterpret_cast<v4f *>(slot0 + (j * 4 + q) * 256) = v4f{o[0], o[1], o[2], o[3]};
+                } else {
+                    if constexpr (MODE == 2) {
+                        if (addp) {                          // rows without a residual stay bit-identical to MODE 0
+                            const v4f pr = *reinterpret_cast<const v4f *>(slot0 + (j * 4 + q) * 256);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) o[c] += pr[c];
+                        }
+                    }
+                    store_out4(out, out_kind, (size_t)t * N, n0 + c0, N, vec, o);
+                }
             }
+    };
+    if (row_ok) {
+        if (!RES || (!rpass && cur.ad == 0)) epilogue(std::integral_constant<int, 0>{});
+        else if (rpass) epilogue(std::integral_constant<int, 1>{});
+        else epilogue(std::integral_constant<int, 2>{});
     }
+    if constexpr (RES) { if (!rpass) nxt.rp = residual_probe_eval(pb); }
     cur = nxt;
     FQL_WSTAMP(ev++, 0);                                     // epilogue issued
     FQL_WSTAMP(ev++, 1);

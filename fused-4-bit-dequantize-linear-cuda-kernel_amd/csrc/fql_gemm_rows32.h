@@ -50,9 +50,7 @@ __device__ unsigned long long fql_trace_buf[8 * 64];         // [block < 8][even
 #define FQL_STAMP(i) do { } while (0)
 #endif
 
-struct Rows32Tile {            // wave-uniform description of one 32-row x BN tile
-    int e, row0, prow0, rows_valid, nt, ok;
-};
+typedef GemmTile Rows32Tile;   // wave-uniform description of one visit of a 32-row x BN tile (fql_gemm_i8.h)
 
 template <int L, int NF, int KG, int DEPTH, int BDEPTH, int OCC>
 __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
@@ -60,10 +58,11 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
     const int32_t *__restrict__ rowsum, const uint8_t *__restrict__ packed,
     const float *__restrict__ scales, const float *__restrict__ zps, void *__restrict__ out, int out_kind,
     const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
-    int E, int T, int K, int Kp, int MBT, int N, int n_tiles, int m_slots)
+    int E, int T, int K, int Kp, int MBT, int N, int n_tiles, int m_slots, float *__restrict__ res_scratch)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = Rows32Cfg<L, NF, KG, DEPTH, BDEPTH, OCC>;
+    constexpr bool RES = FQL_RES_ENABLED && (L >= 2);                           // residual limb set for heavy-tailed rows (fql_gemm_i8.h)
     constexpr int KS = C::KS, D = C::D, NG = C::NG, BD = C::BD;
     constexpr int OOB = 0x7fff0000;                           // a buffer offset past every descriptor: reads zero
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -92,7 +91,7 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
 
     // ---- tile id -> (expert, 32-row block, column block); m-tile major so neighbours share activations in L2
     auto tile_params = [&](int vb) -> Rows32Tile {
-        Rows32Tile tp = {0, 0, 0, 0, 0, 0};
+        Rows32Tile tp = {0, 0, 0, 0, 0, 0, 0, 0};
         if (vb >= n_real) return tp;
         const int tile = xcd_remap(vb, n_real);
         const int ms = tile / n_tiles;
@@ -150,8 +149,9 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
     const int SP = ((KT + KG - 1) / KG + BD - 1) / BD * BD;   // stages per wave per tile, padded to the ring depth
     const size_t wbytes = (size_t)N * (size_t)(K >> 1);
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)limbs, 0, (int)((size_t)L * KB * MBT * 8192), 0x00020000);
+        (void *)limbs, 0, (int)((size_t)(RES ? 2 : 1) * L * KB * MBT * 8192), 0x00020000);
     const int a_stage = MBT * 8192;
+    const int a_limb = KB * MBT * 8192;                       // one limb plane; the residual set starts L planes in
 
     // ---- per-lane offsets that do not depend on the tile: everything tile-specific goes into the scalar offset
     int aoffl[L];
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
     };
     auto a_soff = [&](const Rows32Tile &tp, int s, int ks) -> int {
         const int kt = kg + s * KG;
-        return (tp.ok && kt < KT) ? (tp.prow0 >> 5) * 8192 + kt * a_stage + ks * 1024 : 0;
+        return (tp.ok && kt < KT) ? (tp.prow0 >> 5) * 8192 + kt * a_stage + ks * 1024 + (tp.rp ? L * a_limb : 0) : 0;
     };
     auto w_rsrc = [&](const Rows32Tile &tp) {
         return __builtin_amdgcn_make_buffer_rsrc((void *)(packed + (size_t)tp.e * wbytes), 0, (int)wbytes, 0x00020000);
@@ -192,9 +192,10 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
     v4i afr[D][L];
     float szr[C::SZN];
     int drow[1 + L];                                          // delta bits and limb row sums of this lane's row
+    int d2bits = 0;                                           // delta2 bits of this lane's row (heavy-tailed rows: fql_gemm_i8.h)
     float *szbuf = reinterpret_cast<float *>(lds + C::MAIN_BYTES);
-    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)delta, 0, T * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)rowsum, 0, L * T * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)delta, 0, (RES ? 2 : 1) * T * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)rowsum, 0, (RES ? 2 : 1) * L * T * 4, 0x00020000);
     // the tile's scale / zero-point slice and this lane's row values travel with the tile's first loads, so the
     // epilogue issues no global load (a load there would queue behind the next tile's HBM prefetch)
     auto issue_tile_consts = [&](const Rows32Tile &tp) {
@@ -214,13 +215,16 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
             szr[i] = __builtin_bit_cast(float, vs | vz);
         }
         const int t = (tp.ok && l31 < tp.rows_valid) ? tp.row0 + l31 : 0;
-        drow[0] = __builtin_amdgcn_raw_buffer_load_b32(rsD, t * 4, 0, 0);
+        const int tsel = tp.rp ? T : 0;                       // residual pass: the second set of per-row values
+        drow[0] = __builtin_amdgcn_raw_buffer_load_b32(rsD, (tsel + t) * 4, 0, 0);
 #pragma unroll
-        for (int l = 0; l < L; ++l) drow[1 + l] = __builtin_amdgcn_raw_buffer_load_b32(rsR, (l * T + t) * 4, 0, 0);
+        for (int l = 0; l < L; ++l) drow[1 + l] = __builtin_amdgcn_raw_buffer_load_b32(rsR, (L * tsel + l * T + t) * 4, 0, 0);
+        if (RES) d2bits = __builtin_amdgcn_raw_buffer_load_b32(rsD, (T + t) * 4, 0, 0);
     };
     int ev = 0;
     FQL_STAMP(ev++);                                          // 0: kernel entry (after n_real)
     Rows32Tile cur = tile_params(blockIdx.x);
+    if constexpr (RES) cur.rp = tile_has_residual(delta, T, cur, C::BM, lane) && res_scratch != nullptr;
     FQL_STAMP(ev++);                                          // 1: first tile params
     {
         const __amdgpu_buffer_rsrc_t rs = w_rsrc(cur);
@@ -240,9 +244,15 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
     }
     int parity = 0;
 
-  for (int vb = blockIdx.x; vb < n_real; vb += gridDim.x, parity ^= 1) {
+  for (int vb = blockIdx.x; vb < n_real; parity ^= 1) {     // one iteration per visit (tile, pass): see GemmTile
     FQL_STAMP(ev++);                                          // tile: start
-    const Rows32Tile nxt = tile_params(vb + gridDim.x);
+    Rows32Tile nxt;
+    const bool rpass = RES && cur.rp != 0;
+    if (rpass) { nxt = cur; nxt.rp = 0; nxt.ad = 1; }
+    else { vb += gridDim.x; nxt = tile_params(vb); }
+    // heavy-tail probe of the next tile: issued now, evaluated at the start of the last stage (where nxt is first used)
+    ResidualProbe pb = {0, 0};
+    if constexpr (RES) pb = residual_probe_issue(delta, T, nxt, C::BM, lane, res_scratch != nullptr && !rpass);
     FQL_STAMP(ev++);                                          // tile: next params known
     const __amdgpu_buffer_rsrc_t rs_cur = w_rsrc(cur), rs_nxt = w_rsrc(nxt);
     float *sz = szbuf + parity * 2 * C::BN;
@@ -250,6 +260,7 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
     for (int i = 0; i < C::SZN; ++i)
         if (tid + i * C::THREADS < 2 * C::BN) sz[tid + i * C::THREADS] = szr[i];
     const float d = __builtin_bit_cast(float, drow[0]);
+    const bool addp = RES && (d2bits & 0x7fffffff) != 0;
     float rsum[L];
 #pragma unroll
     for (int l = 0; l < L; ++l) rsum[l] = (float)drow[1 + l];
@@ -272,6 +283,7 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
         // fragment reads
 #pragma unroll
         for (int i = 0; i < C::PIECES; ++i) *reinterpret_cast<v4i *>(slab + wB[i]) = bst[u][i];
+        if constexpr (RES) { if (s + 1 == SP && !rpass) nxt.rp = residual_probe_eval(pb); }
         if (s + 1 == SP) issue_tile_consts(nxt);              // before the younger HBM loads of this boundary
         {   // refill the slot with the stage BD ahead (the next tile's first stages near the end of this one)
             const bool here = s + BD < SP;
@@ -370,24 +382,43 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
     if (kg != 0 || !done.ok || l31 >= done.rows_valid) continue;
     const int t = done.row0 + l31;
     const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & (out_kind == 0 ? 15 : 7)) == 0);
+    // MODE 0 plain tile / 1 residual pass (park float32 results in the scratch slot) / 2 main pass after it (add them)
+    auto epilogue = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        float *slot0 = (MODE == 0) ? nullptr : res_scratch + ((size_t)blockIdx.x * 8 + wave) * (NF * 1024) + lane * 4;
 #pragma unroll
-    for (int j = 0; j < NF; ++j)
+        for (int j = 0; j < NF; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c0 = (ng * NF + j) * 32 + 8 * q + 4 * g;            // column inside the tile
-            const v4f s4 = *reinterpret_cast<const v4f *>(sz + c0);
-            const v4f z4 = *reinterpret_cast<const v4f *>(sz + C::BN + c0);
-            float o[4];
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = (ng * NF + j) * 32 + 8 * q + 4 * g;            // column inside the tile
+                const v4f s4 = *reinterpret_cast<const v4f *>(sz + c0);
+                const v4f z4 = *reinterpret_cast<const v4f *>(sz + C::BN + c0);
+                float o[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float tot = 0.0f;
+                for (int c = 0; c < 4; ++c) {
+                    float tot = 0.0f;
 #pragma unroll
-                for (int l = L - 1; l >= 0; --l)
-                    tot = fmaf(tot, 256.0f, fmaf(-z4[c], rsum[l], (float)acc[l][j][4 * q + c]));
-                o[c] = (tot * d) * s4[c];
+                    for (int l = L - 1; l >= 0; --l)
+                        tot = fmaf(tot, 256.0f, fmaf(-z4[c], rsum[l], (float)acc[l][j][4 * q + c]));
+                    o[c] = (tot * d) * s4[c];
+                }
+                if constexpr (MODE == 1) {
+                    *reinterpret_cast<v4f *>(slot0 + (j * 4 + q) * 256) = v4f{o[0], o[1], o[2], o[3]};
+                } else {
+                    if constexpr (MODE == 2) {
+                        if (addp) {
+                            const v4f pr = *reinterpret_cast<const v4f *>(slot0 + (j * 4 + q) * 256);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) o[c] += pr[c];
+                        }
+                    }
+                    store_out4(out, out_kind, (size_t)t * N, done.nt * C::BN + c0, N, vec, o);
+                }
             }
-            store_out4(out, out_kind, (size_t)t * N, done.nt * C::BN + c0, N, vec, o);
-        }
+    };
+    if (!RES || (done.rp == 0 && done.ad == 0)) epilogue(std::integral_constant<int, 0>{});
+    else if (done.rp) epilogue(std::integral_constant<int, 1>{});
+    else epilogue(std::integral_constant<int, 2>{});
   }
 #endif
 }

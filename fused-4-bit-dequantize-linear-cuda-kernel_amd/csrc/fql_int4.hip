@@ -33,26 +33,51 @@ inline int limbs_of(int precision)
 }
 inline bool is_f8(int precision) { return precision == FQL_PRECISION_FP8; }
 
+inline int compute_units()
+{
+    static int cached = 0;                                   // idempotent; a race only repeats the query
+    if (cached == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;                                         // MI355X
+        n -= n % 8;                                          // keep vb % 8 == blockIdx % 8 (XCD grouping)
+        cached = n > 0 ? n : 8;
+    }
+    return cached;
+}
+
+inline int compute_units_hint() { const int n = compute_units(); return n < 256 ? 256 : n; }
+
 struct Workspace {
     int8_t *limbs;
     float *delta;
     int32_t *rowsum;
+    float *scratch;          // workgroup-private float32 partials of the residual pass (heavy-tailed rows), or nullptr
     size_t bytes;
 };
 
+// Modes with a residual limb set for heavy-tailed rows (csrc/fql_act_quant.h pass 3, csrc/fql_gemm_i8.h): 2 and 3 limbs.
+inline bool has_residual(int L, bool f8) { return L >= 2 && !f8; }
+// Upper bound of the residual-pass scratch over every tile configuration: workgroups x tile floats
+// (8 waves x <= 4 fragments x 4 KiB per workgroup and CU; the small skinny-tile workgroups share a CU's budget).
+inline size_t res_scratch_bytes() { return (size_t)compute_units_hint() * 8 * 4 * 4096; }
+
 inline size_t limb_bytes(int L, int T, int E, int Kp) { return (size_t)L * (Kp / FQL_KB) * row_blocks(T, E) * 8192; }
 
-inline Workspace carve(void *base, int L, int T, int E, int Kp)
+inline Workspace carve(void *base, int L, int T, int E, int Kp, bool res)
 {
     Workspace w;
-    const size_t lb = round16(limb_bytes(L, T, E, Kp));
-    const size_t db = round16((size_t)T * sizeof(float));
-    const size_t rb = round16((size_t)L * T * sizeof(int32_t));
+    const int sets = res ? 2 : 1;
+    const size_t lb = round16(sets * limb_bytes(L, T, E, Kp));
+    const size_t db = round16((size_t)sets * T * sizeof(float));
+    const size_t rb = round16((size_t)sets * L * T * sizeof(int32_t));
     char *p = static_cast<char *>(base);
     w.limbs = reinterpret_cast<int8_t *>(p);
     w.delta = reinterpret_cast<float *>(p + lb);
     w.rowsum = reinterpret_cast<int32_t *>(p + lb + db);
-    w.bytes = lb + db + rb;
+    w.scratch = res ? reinterpret_cast<float *>(p + lb + db + rb) : nullptr;
+    w.bytes = lb + db + rb + (res ? res_scratch_bytes() : 0);
     return w;
 }
 
@@ -107,7 +132,7 @@ inline bool valid_cfg(int cfg) { return (cfg >= 0 && cfg < FQL_NUM_CFG) || (cfg 
 // The MFMA path addresses its operands through 32-bit buffer offsets.
 inline bool mfma_addressable(int L, int T, int E, int K, int N)
 {
-    const size_t a = limb_bytes(L, T, E, padded_k(K));
+    const size_t a = 2 * limb_bytes(L, T, E, padded_k(K));   // with the residual limb set
     const size_t b = ((size_t)N + 256) * (size_t)(K >> 1);
     return a < ((size_t)1 << 31) && b < ((size_t)1 << 31);
 }
@@ -115,20 +140,6 @@ inline bool mfma_addressable(int L, int T, int E, int K, int N)
 inline bool mfma_eligible(int L, int T, int E, int K, int N, const uint8_t *packed)
 {
     return (K % 32 == 0) && aligned16(packed) && mfma_addressable(L, T, E, K, N);
-}
-
-inline int compute_units()
-{
-    static int cached = 0;                                   // idempotent; a race only repeats the query
-    if (cached == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;                                         // MI355X
-        n -= n % 8;                                          // keep vb % 8 == blockIdx % 8 (XCD grouping)
-        cached = n > 0 ? n : 8;
-    }
-    return cached;
 }
 
 inline int dtype_bytes(int dt) { return dt == FQL_DTYPE_F32 ? 4 : 2; }
@@ -187,7 +198,7 @@ int launch_gemm_cfg(const Workspace &w, const uint8_t *packed, const float *scal
     const int cus = compute_units() * (C::NW >= 8 ? 1 : (C::NW == 4 ? 2 : 4));      // 2 waves per SIMD either way
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, w.limbs, w.delta, w.rowsum,
-                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots);
+                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
@@ -212,7 +223,7 @@ int launch_rows32_cfg(const Workspace &w, const uint8_t *packed, const float *sc
     const int cus = compute_units() * C::WG_PER_CU;          // persistent: WG_PER_CU 8-wave workgroups per CU
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, w.limbs, w.delta, w.rowsum,
-                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots);
+                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
@@ -237,7 +248,7 @@ int launch_rows16_cfg(const Workspace &w, const uint8_t *packed, const float *sc
     const int cus = compute_units();
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, w.limbs, w.delta, w.rowsum,
-                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots);
+                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
@@ -356,7 +367,7 @@ int run_mfma(int L, const void *x, int in_dtype, const int32_t *gather, int n_sr
     const int Kp = padded_k(K);
     const int MBT = row_blocks(T, E);
     if (workspace == nullptr || !aligned16(workspace)) return FQL_ERR_WORKSPACE;
-    const Workspace w = carve(workspace, L, T, E, Kp);
+    const Workspace w = carve(workspace, L, T, E, Kp, has_residual(L, f8));
     if (workspace_bytes < w.bytes) return FQL_ERR_WORKSPACE;
     void *zero_out = (tpe != nullptr) ? out : nullptr;
     int rc;
@@ -444,7 +455,7 @@ size_t fql_linear_workspace_bytes(int B, int K, int N, int precision)
     (void)N;
     const int L = limbs_of(precision);
     if (L < 0 || (B <= 4 && !is_f8(precision)) || B <= 0 || K <= 0 || (K % 32) != 0) return 0;
-    Workspace w = carve(nullptr, L, B, 1, padded_k(K));
+    Workspace w = carve(nullptr, L, B, 1, padded_k(K), has_residual(L, is_f8(precision)));
     return w.bytes;
 }
 
@@ -453,7 +464,7 @@ size_t fql_moe_workspace_bytes(int E, int T, int K, int N, int precision)
     (void)N;
     const int L = limbs_of(precision);
     if (L < 0 || T <= 0 || E <= 0 || K <= 0 || (K % 32) != 0) return 0;
-    Workspace w = carve(nullptr, L, T, E, padded_k(K));
+    Workspace w = carve(nullptr, L, T, E, padded_k(K), has_residual(L, is_f8(precision)));
     return w.bytes;
 }
 
@@ -595,7 +606,7 @@ static int f8_entry(const uint8_t *packed, const float *scales, const float *zps
     if (!mfma_eligible(1, T, E, K, N, packed)) return FQL_ERR_ALIGNMENT;      // K % 32 == 0, 16-byte aligned weights
     const int Kp = padded_k(K), MBT = row_blocks(T, E);
     if (workspace == nullptr || !aligned16(workspace)) return FQL_ERR_WORKSPACE;
-    const Workspace w = carve(workspace, 1, T, E, Kp);
+    const Workspace w = carve(workspace, 1, T, E, Kp, false);
     if (workspace_bytes < w.bytes) return FQL_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int mblocks = (tpe == nullptr) ? (T + FQL_MB - 1) / FQL_MB : (T + FQL_MB * E) / FQL_MB;
@@ -715,7 +726,13 @@ size_t fql_act_limb_bytes(int T, int E, int K, int precision)
 {
     const int L = limbs_of(precision);
     if (L < 0 || T <= 0 || E <= 0 || K <= 0) return 0;
-    return limb_bytes(L, T, E, padded_k(K));
+    return (has_residual(L, is_f8(precision)) ? 2 : 1) * limb_bytes(L, T, E, padded_k(K));
+}
+
+size_t fql_gemm_scratch_bytes(int precision)
+{
+    const int L = limbs_of(precision);
+    return (L >= 0 && has_residual(L, is_f8(precision))) ? res_scratch_bytes() : 0;
 }
 
 int fql_act_quant_f32(const float *x, int8_t *limbs, float *delta, int32_t *rowsum,
@@ -731,7 +748,7 @@ int fql_act_quant_f32(const float *x, int8_t *limbs, float *delta, int32_t *rows
     if (tokens_per_expert == nullptr && E != 1) return FQL_ERR_BAD_SHAPE;
     if (!aligned16(limbs)) return FQL_ERR_ALIGNMENT;
     Workspace w;
-    w.limbs = limbs; w.delta = delta; w.rowsum = rowsum; w.bytes = 0;
+    w.limbs = limbs; w.delta = delta; w.rowsum = rowsum; w.scratch = nullptr; w.bytes = 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int Kp = padded_k(K), MBT = row_blocks(T, E);
     if (L == 1) return launch_act_quant<1>(x, FQL_DTYPE_F32, nullptr, 0, w, T, K, Kp, MBT, nullptr, FQL_DTYPE_F32, 0, tokens_per_expert, input_offsets, E, st, false, is_f8(precision));
@@ -767,7 +784,7 @@ int fql_quantize_tensor_f32(const float *w, uint8_t *packed, float *scales, floa
 static int gemm_i8_entry(int cfg, const int8_t *limbs, const float *delta, const int32_t *rowsum,
                          const uint8_t *packed, const float *scales, const float *zps,
                          const int32_t *tokens_per_expert, const int32_t *input_offsets, float *out, int E, int T,
-                         int K, int N, int precision, void *stream)
+                         int K, int N, int precision, void *stream, void *scratch, size_t scratch_bytes)
 {
     const int L = limbs_of(precision);
     if (L < 0) return FQL_ERR_BAD_PRECISION;
@@ -791,6 +808,9 @@ static int gemm_i8_entry(int cfg, const int8_t *limbs, const float *delta, const
     w.delta = const_cast<float *>(delta);
     w.rowsum = const_cast<int32_t *>(rowsum);
     w.bytes = 0;
+    // without (enough) scratch the residual pass of heavy-tailed rows is skipped: the result is then the plain 8L-1 bit one
+    w.scratch = (has_residual(L, is_f8(precision)) && scratch != nullptr && aligned16(scratch) && scratch_bytes >= res_scratch_bytes())
+                    ? static_cast<float *>(scratch) : nullptr;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int Kp = padded_k(K), MBT = row_blocks(T, E);
     if (is_f8(precision))
@@ -805,21 +825,21 @@ static int gemm_i8_entry(int cfg, const int8_t *limbs, const float *delta, const
 int fql_gemm_i8_f32(const int8_t *limbs, const float *delta, const int32_t *rowsum, const uint8_t *packed,
                     const float *scales, const float *zps, const int32_t *tokens_per_expert,
                     const int32_t *input_offsets, float *out, int E, int T, int K, int N, int precision,
-                    void *stream)
+                    void *stream, void *scratch, size_t scratch_bytes)
 {
     return gemm_i8_entry(-1, limbs, delta, rowsum, packed, scales, zps, tokens_per_expert, input_offsets, out, E, T,
-                         K, N, precision, stream);
+                         K, N, precision, stream, scratch, scratch_bytes);
 }
 
 // Tuning hook (not part of the public header): the same call with an explicit tile configuration id.
 FQL_API int fql_tune_gemm_i8_f32(int cfg, const int8_t *limbs, const float *delta, const int32_t *rowsum,
                                  const uint8_t *packed, const float *scales, const float *zps,
                                  const int32_t *tokens_per_expert, const int32_t *input_offsets, float *out, int E,
-                                 int T, int K, int N, int precision, void *stream)
+                                 int T, int K, int N, int precision, void *stream, void *scratch, size_t scratch_bytes)
 {
     if (!(precision == FQL_PRECISION_FP8 ? valid_cfg_f8(cfg) : valid_cfg(cfg))) return FQL_ERR_BAD_SHAPE;
     return gemm_i8_entry(cfg, limbs, delta, rowsum, packed, scales, zps, tokens_per_expert, input_offsets, out, E, T,
-                         K, N, precision, stream);
+                         K, N, precision, stream, scratch, scratch_bytes);
 }
 
 #if defined(FQL_TRACE)

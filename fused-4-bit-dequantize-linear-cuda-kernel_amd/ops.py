@@ -416,15 +416,22 @@ def dequantize_forward(packed_weights, scales, zero_points):
     return w
 
 
+def _sets(prec):
+    """Limb sets of the two-phase buffers: 2 (main + residual of heavy-tailed rows) for 2 / 3 limbs, else 1."""
+    return 2 if _planes(prec) >= 2 else 1
+
+
 def act_quant(x, precision="default", tokens_per_expert=None, input_offsets=None, out=None):
     """Phase 1 of the MFMA path: float32 rows -> int8 limbs in MFMA-fragment order (+ delta, rowsum).
-    Pass the device-side expert arrays for a grouped (MoE) layout, or neither for one group."""
+    Pass the device-side expert arrays for a grouped (MoE) layout, or neither for one group.
+    Returns ``(limbs, delta [S, T], rowsum [S, limbs, T])`` with S = 2 sets for 2 / 3 limbs (set 1 = the residual of
+    heavy-tailed rows, ``delta[1] == 0`` where a row has none) and S = 1 for int8 / fp8 (include/fql_int4.h)."""
     if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2:
         raise RuntimeError("x must be a CUDA float32 [T,K] tensor")
     x = x.contiguous()
     T, K = x.shape
     prec = _precision(precision)
-    nl = _planes(prec)
+    nl, ns = _planes(prec), _sets(prec)
     grouped = tokens_per_expert is not None
     E = tokens_per_expert.numel() if grouped else 1
     L = _native.lib()
@@ -432,8 +439,8 @@ def act_quant(x, precision="default", tokens_per_expert=None, input_offsets=None
         limbs, delta, rowsum = out
     else:
         limbs = torch.zeros(L.fql_act_limb_bytes(T, E, K, prec), dtype=torch.int8, device=x.device)
-        delta = torch.empty((T,), dtype=torch.float32, device=x.device)
-        rowsum = torch.empty((nl, T), dtype=torch.int32, device=x.device)
+        delta = torch.zeros((ns, T), dtype=torch.float32, device=x.device)
+        rowsum = torch.zeros((ns, nl, T), dtype=torch.int32, device=x.device)
     with torch.cuda.device(x.device):
         rc = L.fql_act_quant_f32(x.data_ptr(), limbs.data_ptr(), delta.data_ptr(), rowsum.data_ptr(),
                                  tokens_per_expert.data_ptr() if grouped else None,
@@ -443,18 +450,32 @@ def act_quant(x, precision="default", tokens_per_expert=None, input_offsets=None
     return limbs, delta, rowsum
 
 
+_SCRATCH = {}
+
+
+def gemm_scratch(prec, device):
+    """The residual-pass scratch of phase 2 (one cached buffer per device; contents never outlive a launch)."""
+    n = _native.lib().fql_gemm_scratch_bytes(prec)
+    if n == 0:
+        return None
+    key = (device.index, n)
+    if key not in _SCRATCH:
+        _SCRATCH[key] = torch.empty(n, dtype=torch.uint8, device=device)
+    return _SCRATCH[key]
+
+
 def gemm_i8(limbs, delta, rowsum, packed_weights, scales, zero_points, tokens_per_expert=None,
             input_offsets=None, precision="default", out=None):
     """Phase 2 of the MFMA path: grouped INT4 x INT8-limb GEMM over pre-converted activations
     (``act_quant`` output, produced with the same expert arrays).  ``packed_weights`` [N,K/2] (one
     group) or [E,N,K/2] with device-side ``tokens_per_expert`` / ``input_offsets``."""
-    T = delta.numel()
+    T = delta.shape[-1]
     grouped = packed_weights.dim() == 3
     E = packed_weights.shape[0] if grouped else 1
     N, K2 = packed_weights.shape[-2:]
     K = 2 * K2
     prec = _precision(precision)
-    if _planes(prec) != rowsum.shape[0]:
+    if _planes(prec) != rowsum.shape[-2] or _sets(prec) != delta.shape[0]:
         raise RuntimeError("limb count does not match precision")
     if limbs.numel() < _native.lib().fql_act_limb_bytes(T, E, K, prec):
         raise RuntimeError("limbs were not produced for this T, E, K")
@@ -464,12 +485,32 @@ def gemm_i8(limbs, delta, rowsum, packed_weights, scales, zero_points, tokens_pe
             torch.empty((T, N), dtype=torch.float32, device=dev)
     tpe_ptr = tokens_per_expert.data_ptr() if grouped else None
     off_ptr = input_offsets.data_ptr() if grouped else None
+    scratch = gemm_scratch(prec, dev)
     with torch.cuda.device(dev):
         rc = _native.lib().fql_gemm_i8_f32(limbs.data_ptr(), delta.data_ptr(), rowsum.data_ptr(),
                                            packed_weights.data_ptr(), scales.data_ptr(), zero_points.data_ptr(),
-                                           tpe_ptr, off_ptr, out.data_ptr(), E, T, K, N, prec, _stream_ptr(dev))
+                                           tpe_ptr, off_ptr, out.data_ptr(), E, T, K, N, prec, _stream_ptr(dev),
+                                           None if scratch is None else scratch.data_ptr(),
+                                           0 if scratch is None else scratch.numel())
     _native.check(rc, "fql_gemm_i8_f32")
     return out
+
+
+def tune_gemm_i8(cfg, limbs, delta, rowsum, packed_weights, scales, zero_points, tokens_per_expert, input_offsets, out,
+                 E, T, K, N, precision):
+    """Phase 2 with an explicit tile configuration id (tuning / test hook, not part of the public header)."""
+    import ctypes
+    fn = _native.lib().fql_tune_gemm_i8_f32
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    prec = _precision(precision)
+    dev = limbs.device
+    scratch = gemm_scratch(prec, dev)
+    with torch.cuda.device(dev):
+        return fn(cfg, limbs.data_ptr(), delta.data_ptr(), rowsum.data_ptr(), packed_weights.data_ptr(), scales.data_ptr(),
+                  zero_points.data_ptr(), None if tokens_per_expert is None else tokens_per_expert.data_ptr(),
+                  None if input_offsets is None else input_offsets.data_ptr(), out.data_ptr(), E, T, K, N, prec,
+                  _stream_ptr(dev), None if scratch is None else scratch.data_ptr(), 0 if scratch is None else scratch.numel())
 
 
 # ------------------------------------------------------------------------------------------------ fp8 activations

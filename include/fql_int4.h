@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FQL_VERSION 100 /* 0.1.0 */
+#define FQL_VERSION 200 /* 0.2.0: fp8 activations; residual limb set for heavy-tailed rows (two-phase buffers doubled) */
 
 #if defined(__GNUC__)
 #define FQL_API __attribute__((visibility("default")))
@@ -197,9 +197,20 @@ FQL_API int fql_quantize_tensor_f32(const float *w, uint8_t *packed, float *scal
  *           [limb][k / 256][padded_row / 32][k-step 0..7][lane 0..63][16 B]  (see csrc/fql_act_quant.h;
  *           expert e's rows start at padded row sum_{e'<e} roundup(cnt_e', 32); K is zero-padded to
  *           fql_act_padded_k(K))
- *   delta   [T] float32, rowsum [precision][T] int32 (sum over k of each limb)
+ *   delta   [T] float32, rowsum [limbs][T] int32 (sum over k of each limb)
  *   tokens_per_expert / input_offsets: device arrays as in fql_moe_fwd_f32, or both NULL with E = 1
  *   for one group covering all T rows.  Rows covered by no expert are skipped.
+ *
+ * Heavy-tailed rows (FQL_PRECISION_FAST / _EXACT / _DEFAULT): the limbs are per-ROW block fixed point, so one
+ * outlier element coarsens the quantum of its whole row.  A row whose 8*limbs-1 bits would not carry the mode's
+ * stated precision -- predicted relative output error sqrt(K/12) / ||x/delta||_2 above 1e-6 (3 limbs) or
+ * 2.5e-4 (2 limbs); randn rows never are -- gets a SECOND limb set holding the rounding residual
+ * (x/delta - X) * 2^(8*limbs-1), quantum delta2 = delta * 2^-(8*limbs-1), which the GEMM adds for that row
+ * (16*limbs-2 bits in all).  For these precisions the buffers are therefore doubled:
+ *   limbs   fql_act_limb_bytes() bytes = both sets back to back;  delta [2][T] (delta, delta2; delta2 = 0
+ *   marks a row without residual);  rowsum [2][limbs][T].
+ * FQL_PRECISION_INT8 / _FP8 keep one set.  With _FP8 the plane holds e4m3 bytes, delta the per-row scale
+ * max|x| / 448 and rowsum[0] the float32 bits of the row sum.
  * ------------------------------------------------------------------------------------- */
 FQL_API int fql_act_padded_k(int K);
 
@@ -216,11 +227,17 @@ FQL_API int fql_act_quant_f32(const float *x, int8_t *limbs, float *delta, int32
  * time the dominant kernel alone.  The expert arrays must be the ones phase 1 was given (they fix
  * the limb layout); tokens_per_expert == NULL means one group covering all T rows (E must be 1).  Requires K % 32 == 0 and a 16-byte aligned `packed`
  * (FQL_ERR_ALIGNMENT otherwise).  Rows covered by no expert are left untouched.
+ * `scratch`: fql_gemm_scratch_bytes(precision) bytes, 16-byte aligned -- workgroup-private float32 partials of the
+ * residual pass over tiles that hold heavy-tailed rows (see phase 1).  With scratch == NULL (or too small) that
+ * pass is skipped and such rows keep the plain 8*limbs-1 bit result.
  * ------------------------------------------------------------------------------------- */
+FQL_API size_t fql_gemm_scratch_bytes(int precision);
+
 FQL_API int fql_gemm_i8_f32(const int8_t *limbs, const float *delta, const int32_t *rowsum,
                             const uint8_t *packed, const float *scales, const float *zps,
                             const int32_t *tokens_per_expert, const int32_t *input_offsets,
-                            float *out, int E, int T, int K, int N, int precision, void *stream);
+                            float *out, int E, int T, int K, int N, int precision, void *stream,
+                            void *scratch, size_t scratch_bytes);
 
 /* ---------------------------------------------------------------------------------------
  * Dtype-generic forms of fql_linear_fwd_f32 / fql_moe_fwd_f32 (float16 / bfloat16

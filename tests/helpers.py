@@ -50,13 +50,16 @@ def act_limbs_reference(x, L):
     return digits, delta, digits.sum(axis=2)
 
 
-def decode_limbs(limbs_bytes, L, T, E, K, Kp, counts=None, offsets=None):
+def decode_limbs(limbs_bytes, L, T, E, K, Kp, counts=None, offsets=None, which=0):
     """Invert the fragment-native layout written by the pre-pass:
-    limbs[l][kb][mb][ks][lane][16 B] -> digits [L, T, Kp] in natural k order."""
+    limbs[l][kb][mb][ks][lane][16 B] -> digits [L, T, Kp] in natural k order.  ``which`` = 1 selects the residual
+    set of heavy-tailed rows (2 / 3 limbs only)."""
     raw = np.asarray(limbs_bytes).view(np.int8)
     KB = Kp // 256
-    MBT = raw.size // (L * KB * 8192)
-    arr = raw.reshape(L, KB, MBT, 8, 64, 16)
+    MBT = (T + 32 * E + 128 + 31) // 32                     # the library's row_blocks(T, E) (csrc/fql_int4.hip)
+    one = L * KB * MBT * 8192
+    assert raw.size in (one, 2 * one), (raw.size, one)      # 2 / 3 limbs carry a second (residual) set
+    arr = raw[which * one:(which + 1) * one].reshape(L, KB, MBT, 8, 64, 16)
     # padded row of every t
     if counts is None:
         prow = np.arange(T)
@@ -114,3 +117,30 @@ FP8_ACC_SCALED_REL_FRO = 1e-4
 # (2) format error: e4m3 has a 4-bit significand; per-row scaled randn activations land at ~2.7e-2 relative (Frobenius)
 #     against float32 activations.  Outside the north-star 1e-3 claim, stated on its own.
 FP8_FORMAT_REL_FRO = 6e-2
+
+
+def act_residual_reference(x, L):
+    """numpy restatement of the heavy-tail rule of the pre-pass (csrc/fql_act_quant.h, pass 3): a row is flagged when
+    sum_k (x/delta)^2 < K / (12 P^2), P = 1e-6 (3 limbs) / 2.5e-4 (2 limbs); its residual digits are those of
+    R = rint((x/delta - rint(x/delta)) * 2^(8L-1)), delta2 = delta * 2^-(8L-1).
+    Returns (flag [T] bool, digits [L,T,K], delta2 [T], rowsum2 [L,T]).  (The flag's float32 sum is order dependent in
+    its last bits: callers test rows that are clearly on one side.)"""
+    x = np.asarray(x, dtype=np.float32)
+    T, K = x.shape
+    _, delta, _ = act_limbs_reference(x, L)
+    xs = (x.astype(np.float64) / delta[:, None].astype(np.float64))            # exact: delta is a power of two
+    lim = K * (8.3333e10 if L == 3 else 1.3333e6)
+    flag = ((xs ** 2).sum(axis=1) < lim) & (np.abs(x).max(axis=1) > 0)
+    rb = 8 * L - 1
+    R = np.rint((xs - np.rint(xs)) * float(1 << rb)).astype(np.int64)
+    digits = np.zeros((L, T, K), dtype=np.int64)
+    Xr = R.copy()
+    for l in range(L):
+        if l == L - 1:
+            d = Xr
+        else:
+            d = ((Xr + 128) & 255) - 128
+            Xr = (Xr - d) >> 8
+        digits[l] = d
+    delta2 = np.where(flag, delta.astype(np.float64) * 2.0 ** -rb, 0.0).astype(np.float32)
+    return flag, digits, delta2, digits.sum(axis=2)

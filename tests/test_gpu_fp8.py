@@ -7,8 +7,6 @@ applied in float64 to the decoded e4m3 activations (oracle.reference_linear_fp8)
 torch's float8_e4m3fn casts (tests/test_oracle_golden.py).  Two tolerances, both in tests/helpers.py:
 FP8_ACC_REL_FRO (kernel vs float64 on the SAME fp8 inputs: accumulation only) and FP8_FORMAT_REL_FRO (vs float32
 activations: the format's own rounding)."""
-import ctypes
-
 import numpy as np
 import pytest
 import torch
@@ -97,13 +95,13 @@ def test_fused_fp8_quantiser_is_bit_exact(fq):
     got_bytes = (dig[0].astype(np.int64) & 0xFF).astype(np.uint8)
     want_bytes, want_scale = O.quantize_activations_fp8(x)
     assert covered.all()
-    assert np.array_equal(delta.cpu().numpy(), want_scale)
+    assert np.array_equal(delta[0].cpu().numpy(), want_scale)
     assert np.array_equal(got_bytes[:, :K] & 0x7F, want_bytes & 0x7F)                     # magnitudes
     nz = (want_bytes & 0x7F) != 0
     assert np.array_equal((got_bytes[:, :K] & 0x80)[nz], (want_bytes & 0x80)[nz])         # signs (of non-zeros)
     assert (got_bytes[:, K:] == 0).all()
     want_sum = (O.e4m3_decode(want_bytes).astype(np.float64).sum(axis=1)).astype(np.float32)
-    assert np.array_equal(rowsum.cpu().numpy().view(np.float32)[0], want_sum)
+    assert np.array_equal(rowsum.cpu().numpy().view(np.float32)[0, 0], want_sum)
 
 
 @pytest.mark.parametrize("B,N,K", [(5, 96, 64), (40, 256, 1024), (130, 192, 4096)])
@@ -166,21 +164,15 @@ def test_moe_fp8_grouped(fq, E, N, K, counts, gap):
 
 def test_fp8_tile_configurations_agree(fq):
     """Every tile shape runs the same per-output instruction sequence over K, so the float32 results are bit-identical."""
-    from fused_int4_amd import ops, _native
-    lib = _native.lib()
-    tune = lib.fql_tune_gemm_i8_f32
-    tune.restype = ctypes.c_int
-    tune.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+    from fused_int4_amd import ops
     P, S, Z, cnt, offs, T, rng = make_moe(5, 200, 768, [0, 7, 33, 70, 129], 123)
     x = rng.standard_normal((T, 768)).astype(np.float32)
     dP, dS, dZ, dx, dc, do = dev(P), dev(S), dev(Z), dev(x), dev(cnt), dev(offs)
     limbs, delta, rowsum = ops.act_quant(dx, precision="fp8", tokens_per_expert=dc, input_offsets=do)
-    stream = torch.cuda.current_stream().cuda_stream
     outs = {}
     for cfg in (1, 5, 6, 7, 8, 11, 12):
         out = torch.full((T, 200), float("nan"), dtype=torch.float32, device="cuda")
-        rc = tune(cfg, limbs.data_ptr(), delta.data_ptr(), rowsum.data_ptr(), dP.data_ptr(), dS.data_ptr(), dZ.data_ptr(),
-                  dc.data_ptr(), do.data_ptr(), out.data_ptr(), 5, T, 768, 200, 8, stream)
+        rc = ops.tune_gemm_i8(cfg, limbs, delta, rowsum, dP, dS, dZ, dc, do, out, 5, T, 768, 200, "fp8")
         assert rc == 0, (cfg, rc)
         torch.cuda.synchronize()
         outs[cfg] = out.cpu().numpy()

@@ -81,10 +81,10 @@ def test_activation_limbs_bit_exact(fq, L, prec):
     dig, covered = decode_limbs(limbs.cpu().numpy(), L, T, 1, K, Kp)
     ref_dig, ref_delta, ref_sum = act_limbs_reference(x, L)
     assert covered.all()
-    assert np.array_equal(delta.cpu().numpy(), ref_delta)
+    assert np.array_equal(delta[0].cpu().numpy(), ref_delta)
     assert np.array_equal(dig[:, :, :K], ref_dig)
     assert (dig[:, :, K:] == 0).all()
-    assert np.array_equal(rowsum.cpu().numpy(), ref_sum)
+    assert np.array_equal(rowsum[0].cpu().numpy(), ref_sum)
     assert dig.min() >= -128 and dig.max() <= 127
     # reconstruction error: at most half a unit of the last limb
     X = sum(ref_dig[l] * 256 ** l for l in range(L))
@@ -103,7 +103,7 @@ def test_activation_limbs_grouped_layout(fq):
     ref_dig, ref_delta, _ = act_limbs_reference(x, 3)
     assert covered.sum() == 45
     assert np.array_equal(dig[:, covered], ref_dig[:, covered])
-    assert np.array_equal(delta.cpu().numpy()[covered], ref_delta[covered])
+    assert np.array_equal(delta[0].cpu().numpy()[covered], ref_delta[covered])
 
 
 def test_gpu_quantisers_bit_exact(fq):
@@ -347,26 +347,19 @@ def test_every_tile_configuration_is_bit_identical(fq, prec, tol):
     """The integer dot products are exact, so the tile shape, the K split inside a workgroup and the row
     grouping must not change a single output bit: sweep every compiled configuration (wide tiles 0..,
     short-row-group tiles 100.., decode-size 16-row tiles 200..) through the tuning entry point on a ragged grouped problem."""
-    import ctypes
     from fused_int4_amd import ops, _native
     lib = _native.lib()
-    tune = lib.fql_tune_gemm_i8_f32
-    tune.restype = ctypes.c_int
-    tune.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [ctypes.c_void_p]
     E, N, K = 5, 200, 768                                    # N % 32 != 0, three 256-k stages
     counts = [0, 7, 33, 70, 129]
     P, S, Z, x, cnt, offs = make_moe(E, N, K, counts, 123)
     T = x.shape[0]
     dP, dS, dZ, dx, dc, do = dev(P), dev(S), dev(Z), dev(x), dev(cnt), dev(offs)
     limbs, delta, rowsum = ops.act_quant(dx, precision=prec, tokens_per_expert=dc, input_offsets=do)
-    stream = torch.cuda.current_stream().cuda_stream
     outs = {}
     for cfg in (list(range(lib.fql_tune_num_configs())) + list(range(100, 100 + lib.fql_tune_num_rows32_configs()))
                 + list(range(200, 200 + lib.fql_tune_num_rows16_configs()))):
         out = torch.full((T, N), float("nan"), dtype=torch.float32, device="cuda")
-        rc = tune(cfg, limbs.data_ptr(), delta.data_ptr(), rowsum.data_ptr(), dP.data_ptr(), dS.data_ptr(),
-                  dZ.data_ptr(), dc.data_ptr(), do.data_ptr(), out.data_ptr(), E, T, K, N,
-                  {"exact": 3, "fast": 2, "int8": 1}[prec], stream)
+        rc = ops.tune_gemm_i8(cfg, limbs, delta, rowsum, dP, dS, dZ, dc, do, out, E, T, K, N, prec)
         assert rc == 0, (cfg, rc)
         torch.cuda.synchronize()
         outs[cfg] = out.cpu().numpy()

@@ -8,7 +8,7 @@ from fused_int4_amd import ops, _native
 lib = _native.lib()
 tune = lib.fql_tune_gemm_i8_f32
 tune.restype = ctypes.c_int
-tune.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+tune.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
 rng = np.random.default_rng(123)
 E, N, K = 5, 200, 768
 counts = np.array([0, 7, 33, 70, 129], np.int32)
@@ -26,7 +26,7 @@ for rep in range(2):
     for cfg in (1, 5, 6, 7, 8, 11, 12):
         out = torch.full((T, N), float("nan"), dtype=torch.float32, device="cuda")
         rc = tune(cfg, limbs.data_ptr(), delta.data_ptr(), rowsum.data_ptr(), dP.data_ptr(), dS.data_ptr(), dZ.data_ptr(),
-                  dc.data_ptr(), do.data_ptr(), out.data_ptr(), E, T, K, N, 8, st)
+                  dc.data_ptr(), do.data_ptr(), out.data_ptr(), E, T, K, N, 8, st, None, 0)
         torch.cuda.synchronize()
         o = out.cpu().numpy()
         if rep == 1:

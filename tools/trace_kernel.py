@@ -23,13 +23,13 @@ tpe = torch.full((E,), m, dtype=torch.int32, device=dev); offs = (torch.arange(E
 limbs, delta, rowsum = ops.act_quant(x, precision="exact", tokens_per_expert=tpe, input_offsets=offs)
 lib = _native.lib()
 tune = lib.fql_tune_gemm_i8_f32; tune.restype = ctypes.c_int
-tune.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+tune.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
 out = torch.empty((T, N), device=dev)
 st = torch.cuda.current_stream().cuda_stream
 for i in range(3):
     P, S, Z = sets[i]
     rc = tune(cfg, limbs.data_ptr(), delta.data_ptr(), rowsum.data_ptr(), P.data_ptr(), S.data_ptr(), Z.data_ptr(),
-              tpe.data_ptr(), offs.data_ptr(), out.data_ptr(), E, T, K, N, 3, st)
+              tpe.data_ptr(), offs.data_ptr(), out.data_ptr(), E, T, K, N, 3, st, None, 0)
     assert rc == 0
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 512)()

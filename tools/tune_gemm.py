@@ -29,14 +29,22 @@ def main():
     ap.add_argument("--hidden", type=int, default=4096)
     ap.add_argument("--ffn", type=int, default=11008)
     ap.add_argument("--routing", default="balanced")
+    ap.add_argument("--alt-lib", default="", help="a second build of libfql_int4.so: every configuration is also timed through it (ids 1000 + cfg)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _native.lib()
     tune = lib.fql_tune_gemm_i8_f32
     tune.restype = ctypes.c_int
-    tune.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [ctypes.c_void_p]
+    tune.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 9 + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    alt = None
+    if a.alt_lib:
+        alt = ctypes.CDLL(os.path.abspath(a.alt_lib)).fql_tune_gemm_i8_f32
+        alt.restype = ctypes.c_int
+        alt.argtypes = tune.argtypes
     ncfg = lib.fql_tune_num_configs()
     cfgs = [int(c) for c in a.cfgs.split(",")] if a.cfgs else list(range(ncfg))
+    if alt is not None:
+        cfgs = cfgs + [1000 + c for c in cfgs]
     prec = {"exact": 3, "fast": 2, "int8": 1}[a.precision]
     E, K, N = a.experts, a.hidden, a.ffn
 
@@ -74,10 +82,15 @@ def main():
     flops = 2.0 * T * K * N
     wbytes = En * N * (K // 2)
 
+    scratch = ops.gemm_scratch(prec, dev)
+
     def run(cfg, si, out):
         P, S, Z = sets[si % len(sets)]
-        rc = tune(cfg, limbs.data_ptr(), delta.data_ptr(), rowsum.data_ptr(), P.data_ptr(), S.data_ptr(), Z.data_ptr(),
-                  tp, of, out.data_ptr(), En, T, K, N, prec, stream)
+        fn = alt if cfg >= 1000 else tune
+        cfg = cfg % 1000
+        rc = fn(cfg, limbs.data_ptr(), delta.data_ptr(), rowsum.data_ptr(), P.data_ptr(), S.data_ptr(), Z.data_ptr(),
+                  tp, of, out.data_ptr(), En, T, K, N, prec, stream,
+                  None if scratch is None else scratch.data_ptr(), 0 if scratch is None else scratch.numel())
         assert rc == 0, (cfg, rc)
 
     ref = None
@@ -113,7 +126,7 @@ def main():
     for c, ts in times.items():
         ts = sorted(ts)
         med = ts[len(ts) // 2]
-        print(f"cfg {c:2d}: median {med*1e3:8.1f} us  min {ts[0]*1e3:8.1f} us   {flops/med/1e9:8.1f} TFLOP/s alg   "
+        print(f"cfg {c:4d}: median {med*1e3:8.1f} us  min {ts[0]*1e3:8.1f} us   {flops/med/1e9:8.1f} TFLOP/s alg   "
               f"{wbytes/med/1e6:7.1f} GB/s packed   bitexact={ok[c]}")
 
 
