@@ -41,13 +41,13 @@ struct GemmCfg {
     static constexpr int KS = FQL_KB / 32;                   // MFMA k-steps per weight stage (8)
     static constexpr int D = DEPTH;                          // A prefetch depth in k-steps (register ring)
     static constexpr int B_STAGE = BN * (FQL_KB / 2);        // bytes of packed weights per stage
-    static constexpr int LDS_BYTES = 2 * B_STAGE + 2 * 2 * BN * 4;   // two weight stages + two scale / zero-point slices
+    static constexpr int LDS_BYTES = 2 * B_STAGE + 2 * 3 * BN * 4;   // two weight stages + two scale / zero-point / bias slices
     static constexpr int CPWB = BN / 8 / NW;                 // 1 KiB weight pieces per wave per stage
     static_assert(NW == 8 || NW == 4 || NW == 2, "8 waves (two per SIMD), or small 4 / 2-wave workgroups for skinny tiles");
     static_assert(KS % D == 0, "ring depth must divide the steps per stage");
     static_assert((BN / 8) % NW == 0, "weight pieces must divide evenly over the waves");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-    static constexpr int SZN = (2 * BN + THREADS - 1) / THREADS;      // scale / zero-point floats staged per thread
+    static constexpr int SZN = (3 * BN + THREADS - 1) / THREADS;      // scale / zero-point / bias floats staged per thread
 };
 
 // Debug builds (-DFQL_TRACE, tools/trace_kernel.py): wave 0 of the first 8 workgroups stamps the shader clock
@@ -114,7 +114,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     const int32_t *__restrict__ rowsum, const uint8_t *__restrict__ packed,
     const float *__restrict__ scales, const float *__restrict__ zps, void *__restrict__ out, int out_kind,
     const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
-    int E, int T, int K, int Kp, int MBT, int N, int n_tiles, int m_slots, float *__restrict__ res_scratch)
+    int E, int T, int K, int Kp, int MBT, int N, int n_tiles, int m_slots, float *__restrict__ res_scratch,
+    const float *__restrict__ bias)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub
     using C = GemmCfg<L, WM, WN, NF, DEPTH, BDEPTH>;
@@ -230,16 +231,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
             (void *)(scales + (size_t)tp.e * N), 0, N * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(zps + (size_t)tp.e * N), 0, N * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsBi = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(bias != nullptr ? bias + (size_t)tp.e * N : scales), 0, bias != nullptr ? N * 4 : 0, 0x00020000);
 #pragma unroll
         for (int i = 0; i < C::SZN; ++i) {
-            const int idx = tid + i * C::THREADS;            // < BN: scale of column idx; then zero points
-            const bool is_s = idx < C::BN;
-            const int col = is_s ? idx : idx - C::BN;
-            const int so = (tp.ok && idx < 2 * C::BN) ? 0 : OOB;
+            const int idx = tid + i * C::THREADS;            // < BN: scale of column idx; < 2 BN: zero point; then the bias
+            const int arr = idx < C::BN ? 0 : (idx < 2 * C::BN ? 1 : 2);
+            const int col = idx - arr * C::BN;
+            const int so = (tp.ok && idx < 3 * C::BN) ? 0 : OOB;
             const int vo = (tp.nt * C::BN + col) * 4;
-            const int vs = __builtin_amdgcn_raw_buffer_load_b32(rsS, is_s ? vo : OOB, so, 0);
-            const int vz = __builtin_amdgcn_raw_buffer_load_b32(rsZ, is_s ? OOB : vo, so, 0);
-            szr[i] = __builtin_bit_cast(float, vs | vz);     // the other one read zero
+            const int vs = __builtin_amdgcn_raw_buffer_load_b32(rsS, arr == 0 ? vo : OOB, so, 0);
+            const int vz = __builtin_amdgcn_raw_buffer_load_b32(rsZ, arr == 1 ? vo : OOB, so, 0);
+            const int vb = __builtin_amdgcn_raw_buffer_load_b32(rsBi, arr == 2 ? vo : OOB, so, 0);
+            szr[i] = __builtin_bit_cast(float, vs | vz | vb);   // the other two read zero (no bias: a zero-length descriptor)
         }
     };
 
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
         (void *)(packed + (size_t)e * wbytes), 0, (int)wbytes, 0x00020000);
     const int sB = n0 * (K >> 1);                            // scalar part of this tile's weight offsets
     const int sA = ((cur.prow0 >> 5) + wm) * 8192 + (rpass ? L * a_limb : 0);   // ... and of its activation offsets
-    float *sz = szbuf + parity * 2 * C::BN;
+    float *sz = szbuf + parity * 3 * C::BN;
 
     acc_t acc[L][NF];
 #pragma unroll
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     for (int i = 0; i < C::CPWB; ++i) *reinterpret_cast<v4i *>(lds + wB0 + i * C::NW * 1024) = bst[0][i];
 #pragma unroll
     for (int i = 0; i < C::SZN; ++i)
-        if (tid + i * C::THREADS < 2 * C::BN) sz[tid + i * C::THREADS] = szr[i];
+        if (tid + i * C::THREADS < 3 * C::BN) sz[tid + i * C::THREADS] = szr[i];
 #pragma unroll
     for (int s = 1; s <= BD; ++s)
 #pragma unroll
@@ -441,7 +445,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     GemmTile nxt;
     ResidualProbe pb = {0, 0};
     if (rpass) { nxt = cur; nxt.rp = 0; nxt.ad = 1; }
-    else { vb += gridDim.x; nxt = tile_params(vb); }
+    else { vb += (int)gridDim.x; nxt = tile_params(vb); }
     if constexpr (RES) pb = residual_probe_issue(delta, T, nxt, C::BM, lane, res_scratch != nullptr && !rpass);   // evaluated after the epilogue
     // ---- epilogue: fold zero-point, combine limbs, scale.  The weights are the MFMA's A operand (rows = n)
     //      and the activations its B operand (cols = t), so in the 32x32 C/D layout
@@ -506,6 +510,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
 #pragma unroll
                             for (int c = 0; c < 4; ++c) o[c] += pr[c];
                         }
+                    }
+                    if (bias != nullptr) {                   // (uniform; without a bias the results keep their exact bits)
+                        const v4f b4 = *reinterpret_cast<const v4f *>(sz + 2 * C::BN + c0);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] += b4[c];
                     }
                     store_out4(out, out_kind, (size_t)t * N, n0 + c0, N, vec, o);
                 }

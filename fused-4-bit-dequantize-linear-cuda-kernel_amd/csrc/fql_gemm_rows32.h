@@ -35,9 +35,9 @@ struct Rows32Cfg {
     static constexpr int ACC_BYTES = L * NF * 16 * 64 * 4;    // one wave's accumulators
     static constexpr int RED_BYTES = (KG > 1) ? (KG / 2) * NG * ACC_BYTES : 0;   // first round of the K-group tree
     static constexpr int MAIN_BYTES = (NW * SLAB > RED_BYTES) ? NW * SLAB : RED_BYTES;
-    static constexpr int SZ_BYTES = 2 * 2 * BN * 4;           // scale / zero-point slices of two tiles
+    static constexpr int SZ_BYTES = 2 * 3 * BN * 4;           // scale / zero-point / bias slices of two tiles
     static constexpr int LDS_BYTES = MAIN_BYTES + SZ_BYTES;
-    static constexpr int SZN = (2 * BN + THREADS - 1) / THREADS;
+    static constexpr int SZN = (3 * BN + THREADS - 1) / THREADS;
     static_assert(KG == 1 || KG == 2 || KG == 4 || KG == 8, "K split");
     static_assert(KS % D == 0, "ring depth must divide the steps per stage");
     static_assert(LDS_BYTES * WG_PER_CU <= 160 * 1024, "LDS budget");
@@ -58,7 +58,8 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
     const int32_t *__restrict__ rowsum, const uint8_t *__restrict__ packed,
     const float *__restrict__ scales, const float *__restrict__ zps, void *__restrict__ out, int out_kind,
     const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
-    int E, int T, int K, int Kp, int MBT, int N, int n_tiles, int m_slots, float *__restrict__ res_scratch)
+    int E, int T, int K, int Kp, int MBT, int N, int n_tiles, int m_slots, float *__restrict__ res_scratch,
+    const float *__restrict__ bias)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = Rows32Cfg<L, NF, KG, DEPTH, BDEPTH, OCC>;
@@ -203,16 +204,19 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
             (void *)(scales + (size_t)tp.e * N), 0, N * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(zps + (size_t)tp.e * N), 0, N * 4, 0x00020000);
+const __amdgpu_buffer_rsrc_t rsBi = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(bias != nullptr ? bias + (size_t)tp.e * N : scales), 0, bias != nullptr ? N * 4 : 0, 0x00020000);
 #pragma unroll
         for (int i = 0; i < C::SZN; ++i) {
-            const int idx = tid + i * C::THREADS;
-            const bool is_s = idx < C::BN;
-            const int col = is_s ? idx : idx - C::BN;
-            const int so = (tp.ok && idx < 2 * C::BN) ? 0 : OOB;
+            const int idx = tid + i * C::THREADS;             // < BN: scale; < 2 BN: zero point; then the bias
+            const int arr = idx < C::BN ? 0 : (idx < 2 * C::BN ? 1 : 2);
+            const int col = idx - arr * C::BN;
+            const int so = (tp.ok && idx < 3 * C::BN) ? 0 : OOB;
             const int vo = (tp.nt * C::BN + col) * 4;
-            const int vs = __builtin_amdgcn_raw_buffer_load_b32(rsS, is_s ? vo : OOB, so, 0);
-            const int vz = __builtin_amdgcn_raw_buffer_load_b32(rsZ, is_s ? OOB : vo, so, 0);
-            szr[i] = __builtin_bit_cast(float, vs | vz);
+            const int vs = __builtin_amdgcn_raw_buffer_load_b32(rsS, arr == 0 ? vo : OOB, so, 0);
+            const int vz = __builtin_amdgcn_raw_buffer_load_b32(rsZ, arr == 1 ? vo : OOB, so, 0);
+            const int vb = __builtin_amdgcn_raw_buffer_load_b32(rsBi, arr == 2 ? vo : OOB, so, 0);
+            szr[i] = __builtin_bit_cast(float, vs | vz | vb);
         }
         const int t = (tp.ok && l31 < tp.rows_valid) ? tp.row0 + l31 : 0;
         const int tsel = tp.rp ? T : 0;                       // residual pass: the second set of per-row values
@@ -255,10 +259,10 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
     if constexpr (RES) pb = residual_probe_issue(delta, T, nxt, C::BM, lane, res_scratch != nullptr && !rpass);
     FQL_STAMP(ev++);                                          // tile: next params known
     const __amdgpu_buffer_rsrc_t rs_cur = w_rsrc(cur), rs_nxt = w_rsrc(nxt);
-    float *sz = szbuf + parity * 2 * C::BN;
+    float *sz = szbuf + parity * 3 * C::BN;
 #pragma unroll
     for (int i = 0; i < C::SZN; ++i)
-        if (tid + i * C::THREADS < 2 * C::BN) sz[tid + i * C::THREADS] = szr[i];
+        if (tid + i * C::THREADS < 3 * C::BN) sz[tid + i * C::THREADS] = szr[i];
     const float d = __builtin_bit_cast(float, drow[0]);
     const bool addp = RES && (d2bits & 0x7fffffff) != 0;
     float rsum[L];
@@ -412,7 +416,12 @@ __global__ __launch_bounds__(512, OCC) void gemm_i8_rows32_kernel(
                             for (int c = 0; c < 4; ++c) o[c] += pr[c];
                         }
                     }
-                    store_out4(out, out_kind, (size_t)t * N, done.nt * C::BN + c0, N, vec, o);
+                    if (bias != nullptr) {
+                    const v4f b4 = *reinterpret_cast<const v4f *>(sz + 2 * C::BN + c0);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] += b4[c];
+                }
+                store_out4(out, out_kind, (size_t)t * N, done.nt * C::BN + c0, N, vec, o);
                 }
             }
     };

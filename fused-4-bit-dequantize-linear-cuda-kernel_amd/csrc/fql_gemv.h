@@ -22,7 +22,7 @@
 template <int B>
 __global__ __launch_bounds__(256) void gemv_kernel(
     const float *__restrict__ x, const uint8_t *__restrict__ packed, const float *__restrict__ scales,
-    const float *__restrict__ zps, float *__restrict__ out, int K, int N)
+    const float *__restrict__ zps, float *__restrict__ out, int K, int N, const float *__restrict__ bias)
 {
     extern __shared__ __attribute__((aligned(16))) float xs[];      // [B][K/32][36] + sums
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -105,8 +105,12 @@ __global__ __launch_bounds__(256) void gemv_kernel(
 #pragma unroll
             for (int b = 0; b < B; ++b) {
                 const float dot = wave_sum(acc[r][b]);
-                if (lane == 0 && n < N) out[(size_t)b * N + n] = sc * fmaf(-zp, sx[b], dot);
+                if (lane == 0 && n < N) {
+                    const float v = sc * fmaf(-zp, sx[b], dot);
+                    out[(size_t)b * N + n] = bias != nullptr ? v + bias[n] : v;
+                }
             }
         }
     }
 }
+

@@ -13,7 +13,7 @@ template <int RB>
 __global__ __launch_bounds__(256) void fused_rows_kernel(
     const float *__restrict__ x, const uint8_t *__restrict__ packed, const float *__restrict__ scales,
     const float *__restrict__ zps, float *__restrict__ out, const int32_t *__restrict__ tpe,
-    const int32_t *__restrict__ offs, int T, int K, int N)
+    const int32_t *__restrict__ offs, int T, int K, int N, const float *__restrict__ bias)
 {
     const int e = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void fused_rows_kernel(
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const float s = wave_sum(acc[r]);
-            if (lane == 0 && b0 + r < row_hi) out[(size_t)(b0 + r) * N + n] = s;
+            if (lane == 0 && b0 + r < row_hi) out[(size_t)(b0 + r) * N + n] = bias != nullptr ? s + bias[(size_t)e * N + n] : s;
         }
     }
 }

@@ -16,6 +16,11 @@
 
 namespace {
 
+// Batches up to this many rows take the float32 GEMV kernel, larger ones the MFMA path (measured on MI355X, 4096 -> 11008,
+// product call in a hipGraph: GEMV 9.4 / 12.0 / 19.3 / 23.0 us at B = 1 / 2 / 3 / 4, MFMA path 19.2 / 19.9 / 20.2 us at
+// B = 2 / 3 / 4 and 20.4 us at B = 5..16: profiles/r02_linear_batch_sweep.txt).  Tuning hook below.
+int g_gemv_max_rows = 3;
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline size_t round16(size_t v) { return (v + 15) & ~(size_t)15; }
 inline int padded_k(int K) { return (K + FQL_KB - 1) / FQL_KB * FQL_KB; }
@@ -54,6 +59,7 @@ struct Workspace {
     float *delta;
     int32_t *rowsum;
     float *scratch;          // workgroup-private float32 partials of the residual pass (heavy-tailed rows), or nullptr
+    const float *bias;       // optional per-column bias [N] added to the final outputs (not workspace memory: rides along)
     size_t bytes;
 };
 
@@ -77,6 +83,7 @@ inline Workspace carve(void *base, int L, int T, int E, int Kp, bool res)
     w.delta = reinterpret_cast<float *>(p + lb);
     w.rowsum = reinterpret_cast<int32_t *>(p + lb + db);
     w.scratch = res ? reinterpret_cast<float *>(p + lb + db + rb) : nullptr;
+    w.bias = nullptr;
     w.bytes = lb + db + rb + (res ? res_scratch_bytes() : 0);
     return w;
 }
@@ -198,7 +205,7 @@ int launch_gemm_cfg(const Workspace &w, const uint8_t *packed, const float *scal
     const int cus = compute_units() * (C::NW >= 8 ? 1 : (C::NW == 4 ? 2 : 4));      // 2 waves per SIMD either way
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, w.limbs, w.delta, w.rowsum,
-                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch);
+                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch, w.bias);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
@@ -223,7 +230,7 @@ int launch_rows32_cfg(const Workspace &w, const uint8_t *packed, const float *sc
     const int cus = compute_units() * C::WG_PER_CU;          // persistent: WG_PER_CU 8-wave workgroups per CU
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, w.limbs, w.delta, w.rowsum,
-                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch);
+                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch, w.bias);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
@@ -248,7 +255,7 @@ int launch_rows16_cfg(const Workspace &w, const uint8_t *packed, const float *sc
     const int cus = compute_units();
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, w.limbs, w.delta, w.rowsum,
-                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch);
+                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch, w.bias);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
@@ -362,13 +369,14 @@ inline int choose_cfg(int L, int E, int T, int K, int N, bool grouped)
 int run_mfma(int L, const void *x, int in_dtype, const int32_t *gather, int n_src, const uint8_t *packed,
              const float *scales, const float *zps, void *out, int out_dtype, const int32_t *tpe, const int32_t *offs,
              int E, int T, int K, int N, void *workspace, size_t workspace_bytes, hipStream_t st, bool gated = false,
-             bool f8 = false)
+             bool f8 = false, const float *bias = nullptr)
 {
     const int Kp = padded_k(K);
     const int MBT = row_blocks(T, E);
     if (workspace == nullptr || !aligned16(workspace)) return FQL_ERR_WORKSPACE;
-    const Workspace w = carve(workspace, L, T, E, Kp, has_residual(L, f8));
+    Workspace w = carve(workspace, L, T, E, Kp, has_residual(L, f8));
     if (workspace_bytes < w.bytes) return FQL_ERR_WORKSPACE;
+    w.bias = bias;
     void *zero_out = (tpe != nullptr) ? out : nullptr;
     int rc;
     if (f8) {                                                // float rows -> e4m3 with a per-row scale, one fp8 MFMA pass
@@ -394,14 +402,15 @@ int run_mfma(int L, const void *x, int in_dtype, const int32_t *gather, int n_sr
 }
 
 int run_generic(const float *x, const uint8_t *packed, const float *scales, const float *zps, float *out,
-                const int32_t *tpe, const int32_t *offs, int E, int T, int K, int N, hipStream_t st)
+                const int32_t *tpe, const int32_t *offs, int E, int T, int K, int N, hipStream_t st,
+                const float *bias = nullptr)
 {
     if (tpe != nullptr) {
         hipLaunchKernelGGL(zero_uncovered_rows_kernel, dim3(T), dim3(256), 0, st, out, tpe, offs, E, T, N);
         if (hipGetLastError() != hipSuccess) return FQL_ERR_LAUNCH;
     }
     hipLaunchKernelGGL((fused_rows_kernel<4>), dim3((N + 3) / 4, E), dim3(256), 0, st, x, packed, scales, zps,
-                       out, tpe, offs, T, K, N);
+                       out, tpe, offs, T, K, N, bias);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
@@ -409,7 +418,7 @@ size_t gemv_lds_bytes(int B, int K) { return ((size_t)B * (K >> 5) * GEMV_SEG + 
 
 template <int B>
 int launch_gemv(const float *x, const uint8_t *packed, const float *scales, const float *zps, float *out,
-                int K, int N, hipStream_t st)
+                int K, int N, hipStream_t st, const float *bias)
 {
     const int groups = (N + GEMV_ROWS - 1) / GEMV_ROWS;
     int blocks = (groups + 3) / 4;
@@ -420,7 +429,8 @@ int launch_gemv(const float *x, const uint8_t *packed, const float *scales, cons
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return FQL_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL((gemv_kernel<B>), dim3(blocks), dim3(256), lds, st, x, packed, scales, zps, out, K, N);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((gemv_kernel<B>), dim3(blocks), dim3(256), lds, st, x, packed, scales, zps, out, K, N, bias);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
@@ -454,7 +464,7 @@ size_t fql_linear_workspace_bytes(int B, int K, int N, int precision)
 {
     (void)N;
     const int L = limbs_of(precision);
-    if (L < 0 || (B <= 4 && !is_f8(precision)) || B <= 0 || K <= 0 || (K % 32) != 0) return 0;
+    if (L < 0 || (B <= g_gemv_max_rows && !is_f8(precision)) || B <= 0 || K <= 0 || (K % 32) != 0) return 0;
     Workspace w = carve(nullptr, L, B, 1, padded_k(K), has_residual(L, is_f8(precision)));
     return w.bytes;
 }
@@ -468,9 +478,9 @@ size_t fql_moe_workspace_bytes(int E, int T, int K, int N, int precision)
     return w.bytes;
 }
 
-int fql_linear_fwd_f32(const float *x, const uint8_t *packed, const float *scales, const float *zps,
-                       float *out, int B, int K, int N, int precision, void *workspace,
-                       size_t workspace_bytes, void *stream)
+static int linear_f32_core(const float *x, const uint8_t *packed, const float *scales, const float *zps, const float *bias,
+                           float *out, int B, int K, int N, int precision, void *workspace,
+                           size_t workspace_bytes, void *stream)
 {
     const int L = limbs_of(precision);
     if (L < 0) return FQL_ERR_BAD_PRECISION;
@@ -479,26 +489,43 @@ int fql_linear_fwd_f32(const float *x, const uint8_t *packed, const float *scale
     if (B == 0 || N == 0) return FQL_OK;
     if (!x || !packed || !scales || !zps || !out) return FQL_ERR_NULL_POINTER;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (K == 0) {                                     // empty contraction: out = 0
+    if (K == 0) {                                     // empty contraction: out = 0 (+ bias: the caller adds it; not a path worth a kernel)
+        if (bias != nullptr) return FQL_ERR_BAD_SHAPE;
         return hipMemsetAsync(out, 0, (size_t)B * N * sizeof(float), st) == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
     }
-    if (B <= 4) {
+    const bool mfma_small = B > g_gemv_max_rows && mfma_eligible(L, B, 1, K, N, packed) && workspace != nullptr;
+    if (B <= 4 && !mfma_small) {
         if ((K % 32 == 0) && aligned16(packed) && aligned16(x) && gemv_lds_bytes(B, K) <= 150 * 1024) {
             switch (B) {
-            case 1: return launch_gemv<1>(x, packed, scales, zps, out, K, N, st);
-            case 2: return launch_gemv<2>(x, packed, scales, zps, out, K, N, st);
-            case 3: return launch_gemv<3>(x, packed, scales, zps, out, K, N, st);
-            default: return launch_gemv<4>(x, packed, scales, zps, out, K, N, st);
+            case 1: return launch_gemv<1>(x, packed, scales, zps, out, K, N, st, bias);
+            case 2: return launch_gemv<2>(x, packed, scales, zps, out, K, N, st, bias);
+            case 3: return launch_gemv<3>(x, packed, scales, zps, out, K, N, st, bias);
+            default: return launch_gemv<4>(x, packed, scales, zps, out, K, N, st, bias);
             }
         }
-        return run_generic(x, packed, scales, zps, out, nullptr, nullptr, 1, B, K, N, st);
+        return run_generic(x, packed, scales, zps, out, nullptr, nullptr, 1, B, K, N, st, bias);
     }
     if (is_f8(precision) && !mfma_eligible(L, B, 1, K, N, packed)) return FQL_ERR_ALIGNMENT;   // fp8 exists on the MFMA path only
     if (mfma_eligible(L, B, 1, K, N, packed))
         return run_mfma(L, x, FQL_DTYPE_F32, nullptr, 0, packed, scales, zps, out, FQL_DTYPE_F32, nullptr, nullptr, 1, B, K, N,
-                        workspace, workspace_bytes, st, false, is_f8(precision));
-    return run_generic(x, packed, scales, zps, out, nullptr, nullptr, 1, B, K, N, st);
+                        workspace, workspace_bytes, st, false, is_f8(precision), bias);
+    return run_generic(x, packed, scales, zps, out, nullptr, nullptr, 1, B, K, N, st, bias);
 }
+
+int fql_linear_fwd_f32(const float *x, const uint8_t *packed, const float *scales, const float *zps,
+                       float *out, int B, int K, int N, int precision, void *workspace,
+                       size_t workspace_bytes, void *stream)
+{
+    return linear_f32_core(x, packed, scales, zps, nullptr, out, B, K, N, precision, workspace, workspace_bytes, stream);
+}
+
+int fql_linear_bias_fwd_f32(const float *x, const uint8_t *packed, const float *scales, const float *zps,
+                            const float *bias, float *out, int B, int K, int N, int precision, void *workspace,
+                            size_t workspace_bytes, void *stream)
+{
+    return linear_f32_core(x, packed, scales, zps, bias, out, B, K, N, precision, workspace, workspace_bytes, stream);
+}
+
 
 static int moe_entry(const uint8_t *packed, const float *scales, const float *zps, const float *inputs,
                      const int32_t *row_index, int n_src, const int32_t *tokens_per_expert,
@@ -547,7 +574,7 @@ int fql_native_dtype_supported(int rows, int E, int K, int N, int precision, con
 {
     const int L = limbs_of(precision);
     if (L < 0 || rows <= 0 || E <= 0) return 0;
-    if (!grouped && rows <= 4) return 0;                     // the GEMV path is float32 only
+    if (!grouped && rows <= g_gemv_max_rows) return 0;       // the GEMV path is float32 only
     return mfma_eligible(L, rows, E, K, N, static_cast<const uint8_t *>(packed)) ? 1 : 0;
 }
 
@@ -565,7 +592,7 @@ int fql_linear_fwd(const void *x, int in_dtype, const uint8_t *packed, const flo
     if (K & 1) return FQL_ERR_ODD_K;
     if (B == 0 || N == 0) return FQL_OK;
     if (!x || !packed || !scales || !zps || !out) return FQL_ERR_NULL_POINTER;
-    if (B <= 4 || !mfma_eligible(L, B, 1, K, N, packed)) return FQL_ERR_DTYPE;   // 16-bit I/O exists on the MFMA path only
+    if (B <= g_gemv_max_rows || !mfma_eligible(L, B, 1, K, N, packed)) return FQL_ERR_DTYPE;   // 16-bit I/O exists on the MFMA path only
     return run_mfma(L, x, in_dtype, nullptr, 0, packed, scales, zps, out, out_dtype, nullptr, nullptr, 1, B, K, N,
                     workspace, workspace_bytes, static_cast<hipStream_t>(stream), false, is_f8(precision));
 }
@@ -748,7 +775,7 @@ int fql_act_quant_f32(const float *x, int8_t *limbs, float *delta, int32_t *rows
     if (tokens_per_expert == nullptr && E != 1) return FQL_ERR_BAD_SHAPE;
     if (!aligned16(limbs)) return FQL_ERR_ALIGNMENT;
     Workspace w;
-    w.limbs = limbs; w.delta = delta; w.rowsum = rowsum; w.scratch = nullptr; w.bytes = 0;
+    w.limbs = limbs; w.delta = delta; w.rowsum = rowsum; w.scratch = nullptr; w.bias = nullptr; w.bytes = 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int Kp = padded_k(K), MBT = row_blocks(T, E);
     if (L == 1) return launch_act_quant<1>(x, FQL_DTYPE_F32, nullptr, 0, w, T, K, Kp, MBT, nullptr, FQL_DTYPE_F32, 0, tokens_per_expert, input_offsets, E, st, false, is_f8(precision));
@@ -807,7 +834,9 @@ static int gemm_i8_entry(int cfg, const int8_t *limbs, const float *delta, const
     w.limbs = const_cast<int8_t *>(limbs);
     w.delta = const_cast<float *>(delta);
     w.rowsum = const_cast<int32_t *>(rowsum);
+    w.bias = nullptr;
     w.bytes = 0;
+    // without (enough) scratch the residual pass of heavy-tailed rows is skipped: the result is then the plain 8L-1 bit one
     // without (enough) scratch the residual pass of heavy-tailed rows is skipped: the result is then the plain 8L-1 bit one
     w.scratch = (has_residual(L, is_f8(precision)) && scratch != nullptr && aligned16(scratch) && scratch_bytes >= res_scratch_bytes())
                     ? static_cast<float *>(scratch) : nullptr;
@@ -852,6 +881,7 @@ FQL_API int fql_debug_trace(unsigned long long *dst)
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(fql_trace_buf), sizeof(unsigned long long) * 8 * 64) == hipSuccess ? 0 : -1;
 }
 #endif
+FQL_API int fql_tune_set_gemv_max_rows(int rows) { const int old = g_gemv_max_rows; if (rows >= 0 && rows <= 4) g_gemv_max_rows = rows; return old; }
 FQL_API int fql_tune_num_configs(void) { return FQL_NUM_CFG; }
 FQL_API int fql_tune_num_rows32_configs(void) { return FQL_NUM_ROWS32; }
 FQL_API int fql_tune_num_rows16_configs(void) { return FQL_NUM_ROWS16; }

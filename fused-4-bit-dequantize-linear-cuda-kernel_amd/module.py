@@ -16,20 +16,28 @@ from .quantize import quantize_weights, reference_quantized_linear
 
 
 class QuantizedLinear(nn.Module):
-    def __init__(self, in_features: int, out_features: int, precision: str = "default"):
+    def __init__(self, in_features: int, out_features: int, precision: str = "default", bias: bool = False):
         super().__init__()
         self.in_features = in_features
         self.out_features = out_features
         self.precision = precision
+        # not in the reference (it asserts `bias is None`, python/module.py:84): an optional float32 bias, added in the
+        # kernels' epilogues.  Without one the module's state_dict is exactly the reference's three buffers.
+        if bias:
+            self.register_buffer("bias", torch.zeros(out_features, dtype=torch.float32))
+        else:
+            self.bias = None
         self.register_buffer("packed_weights", torch.zeros(out_features, in_features // 2, dtype=torch.uint8))
         self.register_buffer("scales", torch.zeros(out_features, dtype=torch.float32))
         self.register_buffer("zero_points", torch.zeros(out_features, dtype=torch.float32))
 
     @classmethod
     def from_linear(cls, linear: nn.Linear, precision: str = "default") -> "QuantizedLinear":
-        """Quantise an ``nn.Linear`` (bias unsupported, python/module.py:84)."""
-        assert linear.bias is None, "Bias not supported yet"
-        module = cls(linear.in_features, linear.out_features, precision=precision)
+        """Quantise an ``nn.Linear``.  (The reference asserts there is no bias, python/module.py:84; here a bias is kept
+        as a float32 buffer and added after the quantised matmul.)"""
+        module = cls(linear.in_features, linear.out_features, precision=precision, bias=linear.bias is not None)
+        if linear.bias is not None:
+            module.bias = linear.bias.data.detach().to(torch.float32).clone()
         packed, scales, zero_points = quantize_weights(linear.weight.data)
         module.packed_weights = packed
         module.scales = scales
@@ -39,12 +47,13 @@ class QuantizedLinear(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.is_cuda:
             return self._forward_cuda(x)
-        return reference_quantized_linear(x, self.packed_weights, self.scales, self.zero_points)
+        out = reference_quantized_linear(x, self.packed_weights, self.scales, self.zero_points)
+        return out if self.bias is None else out + self.bias
 
     def _forward_cuda(self, x: torch.Tensor) -> torch.Tensor:
         from . import ops
         return ops.linear_forward(x, self.packed_weights, self.scales, self.zero_points,
-                                  precision=self.precision)
+                                  precision=self.precision, bias=self.bias)
 
     def extra_repr(self) -> str:
         return f"in_features={self.in_features}, out_features={self.out_features}, bits=4"

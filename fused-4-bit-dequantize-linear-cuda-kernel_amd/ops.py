@@ -41,8 +41,9 @@ def _workspace(nbytes, device):
     return ws, ws.data_ptr()
 
 
-def linear_forward(input, packed_weights, scales, zero_points, precision="default"):
-    """Fused 4-bit dequantize + linear forward.  input [K] or [B,K] float32 -> [N] or [B,N]."""
+def linear_forward(input, packed_weights, scales, zero_points, precision="default", bias=None):
+    """Fused 4-bit dequantize + linear forward.  input [K] or [B,K] float32 -> [N] or [B,N].
+    ``bias`` [N] float32 (optional, not in the reference: python/module.py:84) is added in the kernels' epilogues."""
     squeeze = False
     if input.dim() == 1:                                   # :302-306
         input = input.unsqueeze(0)
@@ -82,15 +83,24 @@ def linear_forward(input, packed_weights, scales, zero_points, precision="defaul
         raise RuntimeError("all tensors must be on the same device")
     scales = scales.contiguous()
     zero_points = zero_points.contiguous()
+    if bias is not None:
+        if not bias.is_cuda or bias.device != dev or bias.dtype != torch.float32 or bias.numel() != N:
+            raise RuntimeError("bias must be a float32 tensor with output_dim elements on the input's device")
+        bias = bias.contiguous()
 
     L = _native.lib()
     prec = _precision(precision)
     out = torch.empty((B, N), dtype=torch.float32, device=dev)     # :338
     with torch.cuda.device(dev):
         ws, ws_ptr = _workspace(L.fql_linear_workspace_bytes(B, K, N, prec), dev)
-        rc = L.fql_linear_fwd_f32(input.data_ptr(), packed_weights.data_ptr(), scales.data_ptr(),
-                                  zero_points.data_ptr(), out.data_ptr(), B, K, N, prec,
-                                  ws_ptr, 0 if ws is None else ws.numel(), _stream_ptr(dev))
+        if bias is None:
+            rc = L.fql_linear_fwd_f32(input.data_ptr(), packed_weights.data_ptr(), scales.data_ptr(),
+                                      zero_points.data_ptr(), out.data_ptr(), B, K, N, prec,
+                                      ws_ptr, 0 if ws is None else ws.numel(), _stream_ptr(dev))
+        else:
+            rc = L.fql_linear_bias_fwd_f32(input.data_ptr(), packed_weights.data_ptr(), scales.data_ptr(),
+                                           zero_points.data_ptr(), bias.data_ptr(), out.data_ptr(), B, K, N, prec,
+                                           ws_ptr, 0 if ws is None else ws.numel(), _stream_ptr(dev))
     _native.check(rc, "fql_linear_fwd_f32")
     return out.squeeze(0) if squeeze else out                      # :373-375
 

@@ -108,6 +108,13 @@ FQL_API int fql_linear_fwd_f32(const float *x, const uint8_t *packed, const floa
                        const float *zps, float *out, int B, int K, int N, int precision,
                        void *workspace, size_t workspace_bytes, void *stream);
 
+/* Same with a per-column bias added to the result (the reference asserts `bias is None`,
+ * python/module.py:84):  out[b][n] = (sum_k x[b][k] * (q[n][k] - zp[n]) * scale[n]) + bias[n],  bias [N] float32 or
+ * NULL.  The add is the last operation of the kernels' epilogues (one float32 rounding after the un-biased result). */
+FQL_API int fql_linear_bias_fwd_f32(const float *x, const uint8_t *packed, const float *scales,
+                                    const float *zps, const float *bias, float *out, int B, int K, int N,
+                                    int precision, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Grouped (MoE) INT4 GEMM over rows pre-grouped by expert:
  *   for every expert e:  out[off_e : off_e+cnt_e] = inputs[off_e : off_e+cnt_e] @ dequant(W_e)^T

@@ -127,8 +127,16 @@ def test_module_surface_matches_reference():
     ql2 = QuantizedLinear(128, 64)
     ql2.load_state_dict(sd)
     assert torch.equal(ql2(t(g["x1"])), ql(t(g["x1"])))
-    with pytest.raises(AssertionError):
-        QuantizedLinear.from_linear(torch.nn.Linear(8, 4, bias=True))
+    # the reference asserts `bias is None` (python/module.py:84); here a bias is carried as one more float32 buffer
+    #  and the bias-free module keeps exactly the reference's state_dict
+    lb = torch.nn.Linear(8, 4, bias=True)
+    qb = QuantizedLinear.from_linear(lb)
+    assert sorted(qb.state_dict().keys()) == ["bias", "packed_weights", "scales", "zero_points"]
+    xb = torch.randn(3, 8)
+    assert torch.equal(qb(xb), fq.reference_quantized_linear(xb, qb.packed_weights, qb.scales, qb.zero_points) + lb.bias.data)
+    qb2 = QuantizedLinear(8, 4, bias=True)
+    qb2.load_state_dict(qb.state_dict())
+    assert torch.equal(qb2(xb), qb(xb))
     assert set(fq.__all__) >= {"quantize_weights", "dequantize_weights", "reference_quantized_linear", "QuantizedLinear"}
 
 

@@ -269,6 +269,26 @@ def test_special_rows(fq):
     assert np.isfinite(out[5:]).all()
 
 
+@pytest.mark.parametrize("B,N,K", [(1, 200, 256), (3, 64, 128), (4, 96, 128), (40, 200, 544), (300, 400, 320), (6, 33, 66), (20, 192, 4096)])
+def test_bias_in_every_linear_path(fq, B, N, K):
+    """SURVEY 8f N4 (the reference asserts `bias is None`, python/module.py:84): GEMV, MFMA (wide / 32-row / 16-row
+    tiles by batch size) and the generic kernel all add the bias as their last operation."""
+    from fused_int4_amd import ops
+    x, p, s, z = make_problem(N, K, B, 31 * B + N)
+    bias = np.random.default_rng(B).standard_normal(N).astype(np.float32)
+    base = ops.linear_forward(dev(x), dev(p), dev(s), dev(z)).cpu().numpy()
+    got = ops.linear_forward(dev(x), dev(p), dev(s), dev(z), bias=dev(bias)).cpu().numpy()
+    assert np.array_equal(got, base + bias[None, :])            # one float32 add after the un-biased result
+    assert rel_fro(got, C.linear_f64acc(x, p, s, z) + bias[None, :].astype(np.float64)) < 5e-6
+    lin = torch.nn.Linear(K, N, bias=True)
+    m = fq.QuantizedLinear.from_linear(lin).cuda()
+    assert sorted(m.state_dict().keys()) == ["bias", "packed_weights", "scales", "zero_points"]
+    xt = torch.from_numpy(x)
+    want = m.cpu()(xt)                                          # CPU path: dequantize-then-matmul + bias
+    got_m = m.cuda()(xt.cuda()).cpu()
+    assert torch.allclose(got_m, want, atol=1e-3 if K <= 1024 else 1e-2, rtol=1e-5)
+
+
 # ------------------------------------------------------------------------------ error behaviour (csrc/quantized_linear_kernel.cu:311-335)
 def test_linear_errors(fq):
     from fused_int4_amd import ops

@@ -9,8 +9,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--k", type=int, default=4096); ap.add_argument("--n", type=int, default=11008)
 ap.add_argument("--batches", default="1,2,4,5,8,16,32,64,128,256,512,1024")
 ap.add_argument("--precision", default="exact")
+ap.add_argument("--gemv-max", type=int, default=-1, help="tuning hook: batches up to this many rows take the GEMV kernel")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
+if a.gemv_max >= 0:
+    from fused_int4_amd import _native
+    print("gemv max rows", _native.lib().fql_tune_set_gemv_max_rows(a.gemv_max), "->", a.gemv_max)
 g = torch.Generator(device=dev).manual_seed(0)
 sets = [fq.quantize_weights(torch.randn(a.n, a.k, device=dev, generator=g) * 0.02) for _ in range(8)]
 wbytes = a.n * a.k // 2

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--hidden", type=int, default=4096)
     ap.add_argument("--ffn", type=int, default=11008)
     ap.add_argument("--routing", default="balanced")
+    ap.add_argument("--top-k", type=int, default=2)
+    ap.add_argument("--static-too", action="store_true", help="also time every configuration without scratch: static tile order, no residual pass (ids 2000 + cfg)")
     ap.add_argument("--alt-lib", default="", help="a second build of libfql_int4.so: every configuration is also timed through it (ids 1000 + cfg)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -43,9 +45,12 @@ def main():
         alt.argtypes = tune.argtypes
     ncfg = lib.fql_tune_num_configs()
     cfgs = [int(c) for c in a.cfgs.split(",")] if a.cfgs else list(range(ncfg))
+    base_cfgs = list(cfgs)
     if alt is not None:
-        cfgs = cfgs + [1000 + c for c in cfgs]
-    prec = {"exact": 3, "fast": 2, "int8": 1}[a.precision]
+        cfgs = cfgs + [1000 + c for c in base_cfgs]
+    if a.static_too:
+        cfgs = cfgs + [2000 + c for c in base_cfgs]
+    prec = {"exact": 3, "fast": 2, "int8": 1, "fp8": 8}[a.precision]
     E, K, N = a.experts, a.hidden, a.ffn
 
     g = torch.Generator(device=dev).manual_seed(1)
@@ -59,9 +64,9 @@ def main():
                 P.append(p); S.append(s); Z.append(z)
             sets.append((torch.stack(P), torch.stack(S), torch.stack(Z)))
         if a.routing == "balanced":
-            route = R.balanced_routing(a.tokens, E, 2, device=dev, seed=42)
+            route = R.balanced_routing(a.tokens, E, a.top_k, device=dev, seed=42)
         else:
-            route = R.simulate_routing(a.tokens, E, 2, "skewed", dev, 42)
+            route = R.simulate_routing(a.tokens, E, a.top_k, "skewed", dev, 42)
         x_tok = torch.randn(a.tokens, K, device=dev, generator=g)
         x, tpe, offs, _ = R.dispatch_grouped(x_tok, route.expert_indices, E)
         x = x.contiguous()
@@ -86,11 +91,12 @@ def main():
 
     def run(cfg, si, out):
         P, S, Z = sets[si % len(sets)]
-        fn = alt if cfg >= 1000 else tune
+        fn = alt if 1000 <= cfg < 2000 else tune
+        sc = None if cfg >= 2000 else scratch
         cfg = cfg % 1000
         rc = fn(cfg, limbs.data_ptr(), delta.data_ptr(), rowsum.data_ptr(), P.data_ptr(), S.data_ptr(), Z.data_ptr(),
                   tp, of, out.data_ptr(), En, T, K, N, prec, stream,
-                  None if scratch is None else scratch.data_ptr(), 0 if scratch is None else scratch.numel())
+                  None if sc is None else sc.data_ptr(), 0 if sc is None else sc.numel())
         assert rc == 0, (cfg, rc)
 
     ref = None
