@@ -383,7 +383,10 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
 #pragma unroll
                     for (int i = 0; i < 4; ++i) sums[l] = __builtin_amdgcn_sdot4((int)w[l][i], 0x01010101, sums[l], false);
                     int8_t *dst = base + (((size_t)l * KB + kb) * MBT + mb) * 8192 + ((ks * 64) + g * 32 + r32) * 16;
-                    if (store) *reinterpret_cast<v4i *>(dst) = v4i{(int)w[l][0], (int)w[l][1], (int)w[l][2], (int)w[l][3]};
+                    if (store) {
+                        if (FQL_LIMB_WT) store16_wt(dst, v4i{(int)w[l][0], (int)w[l][1], (int)w[l][2], (int)w[l][3]});
+                        else *reinterpret_cast<v4i *>(dst) = v4i{(int)w[l][0], (int)w[l][1], (int)w[l][2], (int)w[l][3]};
+                    }
                 }
             }
         }

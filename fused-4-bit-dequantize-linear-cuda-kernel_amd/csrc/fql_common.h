@@ -72,13 +72,37 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f)
     u += 0x7FFFu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
 }
+// Write-through (sc1) 16-byte store: the line goes straight to memory and is dropped from the XCD's L2, so nothing of
+// it is left dirty for the kernel-boundary write-back (MI355X_MICROARCH.md, "boundary": + bytes / 6 TB/s for what the
+// predecessor leaves dirty).  Used for data this kernel never reads again.  The s_nop keeps the data registers intact
+// until the store has read them (cdna_hip_programming.md 5.7 item 1).
+#ifndef FQL_OUT_WT
+#define FQL_OUT_WT 0           // GEMM outputs write-through (A/B knob)
+#endif
+#ifndef FQL_LIMB_WT
+#define FQL_LIMB_WT 0          // pre-pass limb stores write-through (A/B knob)
+#endif
+__device__ __forceinline__ void store16_wt(void *p, v4f v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store16_wt(void *p, v4i v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
 // Four consecutive outputs of row `row_elems` (= t * N) starting at column n.  `vec`: N % 4 == 0 and a suitably
 // aligned base, so the four columns exist and one wide store is legal.
 __device__ __forceinline__ void store_out4(void *out, int kind, size_t row_elems, int n, int N, bool vec, const float (&o)[4])
 {
     if (kind == 0) {
         float *p = reinterpret_cast<float *>(out) + row_elems + n;
-        if (vec) { if (n < N) *reinterpret_cast<v4f *>(p) = v4f{o[0], o[1], o[2], o[3]}; }
+        if (vec) {
+            if (n < N) {
+                if (FQL_OUT_WT) store16_wt(p, v4f{o[0], o[1], o[2], o[3]});
+                else *reinterpret_cast<v4f *>(p) = v4f{o[0], o[1], o[2], o[3]};
+            }
+        }
         else {
 #pragma unroll
             for (int c = 0; c < 4; ++c) if (n + c < N) p[c] = o[c];

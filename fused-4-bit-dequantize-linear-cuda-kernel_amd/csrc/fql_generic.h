@@ -54,6 +54,59 @@ __global__ __launch_bounds__(256) void fused_rows_kernel(
     }
 }
 
+// Per-GROUP scales and zero points along K (not in the reference, whose quantisation is per row:
+// python/quantize.py:73-80): scales / zps are [E][N][K / group] and
+//   out[t][n] = sum_k x[t][k] * (q[n][k] - zp[n][k / group]) * scale[n][k / group]        (float32 FMA, as above).
+// Functional path for GPTQ / AWQ-style checkpoints: the same one-wave-per-output-row kernel, the group's two constants
+// looked up per packed byte (L1 hits).  Not a fast path: the integer MFMA kernels need ONE scale per output row to
+// keep their accumulators integer across K (a float flush per group is VALU-bound next to the MFMAs).
+template <int RB>
+__global__ __launch_bounds__(256) void fused_rows_group_kernel(
+    const float *__restrict__ x, const uint8_t *__restrict__ packed, const float *__restrict__ scales,
+    const float *__restrict__ zps, float *__restrict__ out, const int32_t *__restrict__ tpe,
+    const int32_t *__restrict__ offs, int T, int K, int N, int group, const float *__restrict__ bias)
+{
+    const int e = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    int row_lo = 0, row_hi = T;
+    if (tpe != nullptr) {
+        long long lo = offs[e], hi = lo + (long long)tpe[e];
+        row_lo = (int)(lo < 0 ? 0 : lo);
+        row_hi = (int)(hi > T ? T : hi);
+    }
+    const int K2 = K >> 1, G = K / group;
+    const uint8_t *prow = packed + ((size_t)e * N + n) * K2;
+    const float *srow = scales + ((size_t)e * N + n) * G;
+    const float *zrow = zps + ((size_t)e * N + n) * G;
+    for (int b0 = row_lo; b0 < row_hi; b0 += RB) {
+        float acc[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = 0.0f;
+        for (int j = lane; j < K2; j += 64) {
+            const uint8_t byte = prow[j];
+            const int g = (2 * j) / group;                    // group is even: both nibbles of a byte share it
+            const float sc = srow[g], zp = zrow[g];
+            const float w0 = ((float)(byte & 0x0F) - zp) * sc;
+            const float w1 = ((float)(byte >> 4) - zp) * sc;
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                if (b0 + r < row_hi) {
+                    const float *xr = x + (size_t)(b0 + r) * K;
+                    acc[r] = fmaf(w0, xr[2 * j], acc[r]);
+                    acc[r] = fmaf(w1, xr[2 * j + 1], acc[r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const float s = wave_sum(acc[r]);
+            if (lane == 0 && b0 + r < row_hi) out[(size_t)(b0 + r) * N + n] = bias != nullptr ? s + bias[(size_t)e * N + n] : s;
+        }
+    }
+}
+
 // Zero the rows of out[T][N] that no expert range covers (torch::zeros semantics of the reference's
 // MoE wrapper, csrc/moe_int4_kernel.cu:109).  Only the generic path launches this; the MFMA path
 // folds it into the activation pre-pass.

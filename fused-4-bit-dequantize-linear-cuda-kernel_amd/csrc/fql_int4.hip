@@ -664,6 +664,46 @@ int fql_linear_fwd_f8(const uint8_t *x_e4m3, const float *act_scales, const uint
                     workspace_bytes, stream);
 }
 
+// ---- per-group scales along K (functional path: csrc/fql_generic.h)
+static int group_entry(const float *x, const uint8_t *packed, const float *scales, const float *zps, const float *bias,
+                       float *out, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int N, int group,
+                       void *stream)
+{
+    if (E <= 0 || T < 0 || K < 0 || N < 0) return FQL_ERR_BAD_SHAPE;
+    if (K & 1) return FQL_ERR_ODD_K;
+    if (group <= 0 || (group & 1) || K % group != 0) return FQL_ERR_BAD_SHAPE;     // even groups that tile K
+    if (T == 0 || N == 0) return FQL_OK;
+    if (!x || !packed || !scales || !zps || !out) return FQL_ERR_NULL_POINTER;
+    if ((tpe == nullptr) != (offs == nullptr)) return FQL_ERR_NULL_POINTER;
+    if (tpe == nullptr && E != 1) return FQL_ERR_BAD_SHAPE;
+    if (E > 65535) return FQL_ERR_BAD_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (K == 0) return hipMemsetAsync(out, 0, (size_t)T * N * sizeof(float), st) == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
+    (void)hipGetLastError();
+    if (tpe != nullptr) {
+        hipLaunchKernelGGL(zero_uncovered_rows_kernel, dim3(T), dim3(256), 0, st, out, tpe, offs, E, T, N);
+        if (hipGetLastError() != hipSuccess) return FQL_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL((fused_rows_group_kernel<4>), dim3((N + 3) / 4, E), dim3(256), 0, st, x, packed, scales, zps, out,
+                       tpe, offs, T, K, N, group, bias);
+    return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
+}
+
+int fql_linear_group_fwd_f32(const float *x, const uint8_t *packed, const float *scales, const float *zps,
+                             const float *bias, float *out, int B, int K, int N, int group_size, void *stream)
+{
+    return group_entry(x, packed, scales, zps, bias, out, nullptr, nullptr, 1, B, K, N, group_size, stream);
+}
+
+int fql_moe_group_fwd_f32(const uint8_t *packed, const float *scales, const float *zps, const float *inputs,
+                          const int32_t *tokens_per_expert, const int32_t *input_offsets, float *out, int E, int T,
+                          int K, int N, int group_size, void *stream)
+{
+    if (!tokens_per_expert || !input_offsets) return FQL_ERR_NULL_POINTER;
+    return group_entry(inputs, packed, scales, zps, nullptr, out, tokens_per_expert, input_offsets, E, T, K, N, group_size,
+                       stream);
+}
+
 int fql_moe_gated_fwd_f32(const uint8_t *packed, const float *scales, const float *zps, const float *gate_up,
                           const int32_t *tokens_per_expert, const int32_t *input_offsets, float *out, int E, int T,
                           int K, int N, int precision, void *workspace, size_t workspace_bytes, void *stream)

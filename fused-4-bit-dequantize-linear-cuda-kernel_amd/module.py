@@ -16,11 +16,14 @@ from .quantize import quantize_weights, reference_quantized_linear
 
 
 class QuantizedLinear(nn.Module):
-    def __init__(self, in_features: int, out_features: int, precision: str = "default", bias: bool = False):
+    def __init__(self, in_features: int, out_features: int, precision: str = "default", bias: bool = False,
+                 group_size: int | None = None):
         super().__init__()
         self.in_features = in_features
         self.out_features = out_features
         self.precision = precision
+        # not in the reference (per-row only, python/quantize.py:73-80): per-group scales along K, buffers [N, K / group_size]
+        self.group_size = None if group_size in (None, in_features) else group_size
         # not in the reference (it asserts `bias is None`, python/module.py:84): an optional float32 bias, added in the
         # kernels' epilogues.  Without one the module's state_dict is exactly the reference's three buffers.
         if bias:
@@ -28,17 +31,19 @@ class QuantizedLinear(nn.Module):
         else:
             self.bias = None
         self.register_buffer("packed_weights", torch.zeros(out_features, in_features // 2, dtype=torch.uint8))
-        self.register_buffer("scales", torch.zeros(out_features, dtype=torch.float32))
-        self.register_buffer("zero_points", torch.zeros(out_features, dtype=torch.float32))
+        sz_shape = (out_features,) if self.group_size is None else (out_features, in_features // self.group_size)
+        self.register_buffer("scales", torch.zeros(sz_shape, dtype=torch.float32))
+        self.register_buffer("zero_points", torch.zeros(sz_shape, dtype=torch.float32))
 
     @classmethod
-    def from_linear(cls, linear: nn.Linear, precision: str = "default") -> "QuantizedLinear":
+    def from_linear(cls, linear: nn.Linear, precision: str = "default", group_size: int | None = None) -> "QuantizedLinear":
         """Quantise an ``nn.Linear``.  (The reference asserts there is no bias, python/module.py:84; here a bias is kept
         as a float32 buffer and added after the quantised matmul.)"""
-        module = cls(linear.in_features, linear.out_features, precision=precision, bias=linear.bias is not None)
+        module = cls(linear.in_features, linear.out_features, precision=precision, bias=linear.bias is not None,
+                     group_size=group_size)
         if linear.bias is not None:
             module.bias = linear.bias.data.detach().to(torch.float32).clone()
-        packed, scales, zero_points = quantize_weights(linear.weight.data)
+        packed, scales, zero_points = quantize_weights(linear.weight.data, group_size=module.group_size)
         module.packed_weights = packed
         module.scales = scales
         module.zero_points = zero_points

@@ -75,6 +75,9 @@ def linear_forward(input, packed_weights, scales, zero_points, precision="defaul
     N, packed_dim = packed_weights.shape
     if packed_dim != K // 2 or K % 2 != 0:
         raise RuntimeError("packed_weights dim 1 must be input_dim / 2")
+    if scales.dim() == 2 and scales.shape[1] > 1:           # per-group scales along K (functional path)
+        out = _linear_group_forward(input, packed_weights, scales, zero_points, bias)
+        return out.squeeze(0) if squeeze else out
     # not checked by the reference (silent UB there); checked here
     if scales.numel() != N or zero_points.numel() != N:
         raise RuntimeError("scales and zero_points must have output_dim elements")
@@ -103,6 +106,57 @@ def linear_forward(input, packed_weights, scales, zero_points, precision="defaul
                                            ws_ptr, 0 if ws is None else ws.numel(), _stream_ptr(dev))
     _native.check(rc, "fql_linear_fwd_f32")
     return out.squeeze(0) if squeeze else out                      # :373-375
+
+
+def _linear_group_forward(input, packed_weights, scales, zero_points, bias):
+    """Per-group scales along K (``scales`` / ``zero_points`` [N, K / group_size]): fql_linear_group_fwd_f32."""
+    B, K = input.shape
+    N = packed_weights.shape[0]
+    if tuple(scales.shape) != tuple(zero_points.shape) or scales.shape[0] != N or K % scales.shape[1] != 0:
+        raise RuntimeError("per-group scales and zero_points must be [output_dim, input_dim / group_size]")
+    group = K // scales.shape[1]
+    if group % 2 != 0:
+        raise RuntimeError("group_size must be even")
+    dev = input.device
+    for t in (packed_weights, scales, zero_points):
+        if t.device != dev:
+            raise RuntimeError("all tensors must be on the same device")
+    if bias is not None:
+        if bias.device != dev or bias.dtype != torch.float32 or bias.numel() != N:
+            raise RuntimeError("bias must be a float32 tensor with output_dim elements on the input's device")
+        bias = bias.contiguous()
+    out = torch.empty((B, N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _native.lib().fql_linear_group_fwd_f32(input.data_ptr(), packed_weights.data_ptr(), scales.contiguous().data_ptr(),
+                                                    zero_points.contiguous().data_ptr(),
+                                                    None if bias is None else bias.data_ptr(), out.data_ptr(), B, K, N,
+                                                    group, _stream_ptr(dev))
+    _native.check(rc, "fql_linear_group_fwd_f32")
+    return out
+
+
+def moe_group_forward(packed_weights, scales, zero_points, inputs, tokens_per_expert, input_offsets):
+    """Grouped per-expert INT4 GEMM with per-GROUP scales along K: ``scales`` / ``zero_points`` [E, N, K / group_size].
+    Functional path (include/fql_int4.h); rows no expert covers are zero."""
+    if not inputs.is_cuda or inputs.dtype != torch.float32 or inputs.dim() != 2 or packed_weights.dim() != 3:
+        raise RuntimeError("inputs must be a CUDA float32 [T, K] tensor and packed_weights [E, N, K/2]")
+    E, N, K2 = packed_weights.shape
+    T, K = inputs.shape
+    if K != 2 * K2 or scales.dim() != 3 or tuple(scales.shape[:2]) != (E, N) or tuple(zero_points.shape) != tuple(scales.shape) \
+            or K % scales.shape[2] != 0:
+        raise RuntimeError("per-group scales and zero_points must be [E, N, K / group_size]")
+    group = K // scales.shape[2]
+    dev = inputs.device
+    tpe = tokens_per_expert.to(device=dev, dtype=torch.int32).contiguous()
+    offs = input_offsets.to(device=dev, dtype=torch.int32).contiguous()
+    out = torch.empty((T, N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _native.lib().fql_moe_group_fwd_f32(packed_weights.contiguous().data_ptr(), scales.contiguous().data_ptr(),
+                                                 zero_points.contiguous().data_ptr(), inputs.contiguous().data_ptr(),
+                                                 tpe.data_ptr(), offs.data_ptr(), out.data_ptr(), E, T, K, N, group,
+                                                 _stream_ptr(dev))
+    _native.check(rc, "fql_moe_group_fwd_f32")
+    return out
 
 
 def moe_forward(packed_weights, scales, zero_points, inputs, expert_ids, tokens_per_expert,

@@ -37,15 +37,24 @@ def unpack_nibbles(packed: torch.Tensor) -> torch.Tensor:
     return q
 
 
-def quantize_weights(weight_fp32: torch.Tensor, num_bits: int = 4):
+def quantize_weights(weight_fp32: torch.Tensor, num_bits: int = 4, group_size: int | None = None):
     """``[N, K]`` float32 -> ``(packed [N, K/2] uint8, scales [N], zero_points [N])``.
 
     Per row: ``scale = (max - min) / qmax``; a constant row uses ``max(|v|, 1) / qmax``; scale is
     floored at 1e-8; ``zp = clamp(round(-min / scale), 0, qmax)``;
     ``q = clamp(round(w / scale + zp), 0, qmax)`` with round-half-to-even.
+
+    ``group_size`` (not in the reference): the same rule applied to every run of ``group_size``
+    consecutive k of a row -- ``scales`` / ``zero_points`` become ``[N, K / group_size]`` (the GPTQ / AWQ layout).
     """
     assert weight_fp32.ndim == 2, "Weight must be 2D [output_dim, input_dim]"
     assert weight_fp32.shape[1] % 2 == 0, "input_dim must be even for packing"
+    if group_size is not None and group_size != weight_fp32.shape[1]:
+        N, K = weight_fp32.shape
+        assert group_size > 0 and group_size % 2 == 0 and K % group_size == 0, "group_size must be even and divide input_dim"
+        G = K // group_size
+        p, s, z = quantize_weights(weight_fp32.reshape(N * G, group_size).contiguous(), num_bits)
+        return p.reshape(N, K // 2), s.reshape(N, G), z.reshape(N, G)
     if weight_fp32.is_cuda and num_bits == 4 and weight_fp32.dtype == torch.float32:
         from . import ops                       # HIP quantiser: bit-exact with the host path below
         return ops.quantize_rows(weight_fp32)
@@ -60,7 +69,14 @@ def quantize_weights(weight_fp32: torch.Tensor, num_bits: int = 4):
 
 
 def dequantize_weights(packed_uint8: torch.Tensor, scales: torch.Tensor, zero_points: torch.Tensor):
-    """``[N, K/2]`` packed bytes -> ``[N, K]`` float32: ``(q - zp) * scale``."""
+    """``[N, K/2]`` packed bytes -> ``[N, K]`` float32: ``(q - zp) * scale``; ``scales`` / ``zero_points`` ``[N]``
+    (per row, the reference's format) or ``[N, K / group_size]`` (per group along K)."""
+    if scales.dim() == 2:                                   # per-group: the per-row rule on [N * G, group_size]
+        N, G = scales.shape
+        K = packed_uint8.shape[1] * 2
+        w = dequantize_weights(packed_uint8.reshape(N * G, K // G // 2).contiguous(), scales.reshape(-1).contiguous(),
+                               zero_points.reshape(-1).contiguous())
+        return w.reshape(N, K)
     if packed_uint8.is_cuda:
         from . import ops
         return ops.dequantize_forward(packed_uint8, scales, zero_points)

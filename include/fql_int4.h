@@ -173,6 +173,25 @@ FQL_API int fql_linear_fwd_f8(const uint8_t *x_e4m3, const float *act_scales, co
                               int N, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Per-GROUP scales and zero points along K (the layout GPTQ / AWQ-style INT4 checkpoints use;
+ * NOT in the reference, whose quantisation is per output row, python/quantize.py:73-80):
+ *
+ *   out[t][n] = sum_k x[t][k] * (q[n][k] - zps[n][k / group_size]) * scales[n][k / group_size]   (+ bias[n])
+ *
+ *   scales, zps [N][K / group_size] float32 ([E][N][K / group_size] for the grouped form); group_size even, divides K.
+ * A FUNCTIONAL path (one wave per output row, float32 FMA), any shape, no workspace: the integer MFMA kernels need a
+ * single scale per output row.  Per-row quantisation (group_size == K) stays on the fast entry points above.
+ * ------------------------------------------------------------------------------------- */
+FQL_API int fql_linear_group_fwd_f32(const float *x, const uint8_t *packed, const float *scales,
+                                     const float *zps, const float *bias, float *out, int B, int K, int N,
+                                     int group_size, void *stream);
+
+FQL_API int fql_moe_group_fwd_f32(const uint8_t *packed, const float *scales, const float *zps,
+                                  const float *inputs, const int32_t *tokens_per_expert,
+                                  const int32_t *input_offsets, float *out, int E, int T, int K, int N,
+                                  int group_size, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Format helpers on the device (same unpack code path as the GEMM kernels; bit-exact).
  *   fql_unpack_u8     : q[i][2j] = packed[i][j] & 15, q[i][2j+1] = packed[i][j] >> 4
  *                       (python/quantize.py:152-163)

@@ -302,3 +302,29 @@ def reference_moe_grouped_fp8(xbytes, act_scale, packed, scales, zero_points, to
             sc = None if act_scale is None else np.asarray(act_scale)[lo:hi]
             out[lo:hi] = reference_linear_fp8(np.asarray(xbytes)[lo:hi], sc, packed[e], scales[e], zero_points[e])
     return out
+
+
+# --------------------------------------------------------------------------------------
+# per-GROUP scales along K.  NOT in the reference (per row only, python/quantize.py:73-80): the
+# reference's per-row rule (quantize_weights above, pinned) applied to every run of `group_size` consecutive k.
+# --------------------------------------------------------------------------------------
+def quantize_weights_grouped(weight_fp32, group_size):
+    w = np.ascontiguousarray(np.asarray(weight_fp32, dtype=F32))
+    N, K = w.shape
+    assert group_size % 2 == 0 and K % group_size == 0
+    G = K // group_size
+    p, s, z = quantize_weights(w.reshape(N * G, group_size))
+    return p.reshape(N, K // 2), s.reshape(N, G), z.reshape(N, G)
+
+
+def dequantize_weights_grouped(packed, scales, zero_points):
+    packed = np.asarray(packed, dtype=np.uint8)
+    N, G = np.asarray(scales).shape
+    K = packed.shape[1] * 2
+    q = unpack_nibbles(packed).astype(F32).reshape(N, G, K // G)
+    return ((q - np.asarray(zero_points, F32)[:, :, None]) * np.asarray(scales, F32)[:, :, None]).reshape(N, K)
+
+
+def reference_linear_grouped(x, packed, scales, zero_points):
+    """dequantize-then-matmul (python/quantize.py:176-202) with per-group constants, accumulated in float64."""
+    return np.asarray(x, np.float64) @ dequantize_weights_grouped(packed, scales, zero_points).astype(np.float64).T

@@ -274,3 +274,31 @@ def test_gated_ffn_oracle_matches_torch_float64():
         want[rows] = (torch.nn.functional.silu(gu[:, :F]) * gu[:, F:]) @ wd.T
     assert np.allclose(ref, want.numpy(), rtol=1e-12, atol=1e-12)
     assert ffn.total_memory_bytes == sum(b.numel() * b.element_size() for b in ffn.buffers())
+
+
+def test_per_group_quantisation_cpu():
+    """SURVEY 8f N3 (not in the reference): per-group scales along K = the reference's per-row rule on every group;
+    group_size == K reproduces the per-row result bit for bit; the module keeps [N, K / group_size] buffers."""
+    import numpy as np
+    from oracle import oracle as O
+    import fused_int4_amd as fq
+    torch.manual_seed(3)
+    w = torch.randn(24, 256)
+    p, s, z = fq.quantize_weights(w, group_size=64)
+    assert p.shape == (24, 128) and s.shape == (24, 4) and z.shape == (24, 4)
+    po, so, zo = O.quantize_weights_grouped(w.numpy(), 64)
+    assert np.array_equal(p.numpy(), po) and np.array_equal(s.numpy(), so) and np.array_equal(z.numpy(), zo)
+    assert np.array_equal(fq.dequantize_weights(p, s, z).numpy(), O.dequantize_weights_grouped(po, so, zo))
+    p1, s1, z1 = fq.quantize_weights(w)
+    pk, sk, zk = fq.quantize_weights(w, group_size=256)
+    assert torch.equal(p1, pk) and torch.equal(s1, sk) and torch.equal(z1, zk)
+    # smaller groups -> smaller reconstruction error
+    err_row = (fq.dequantize_weights(p1, s1, z1) - w).norm()
+    err_grp = (fq.dequantize_weights(p, s, z) - w).norm()
+    assert err_grp < err_row
+    lin = torch.nn.Linear(256, 24, bias=False)
+    m = fq.QuantizedLinear.from_linear(lin, group_size=64)
+    assert m.scales.shape == (24, 4) and m.extra_repr().startswith("in_features=256")
+    x = torch.randn(5, 256)
+    ref = O.reference_linear_grouped(x.numpy(), m.packed_weights.numpy(), m.scales.numpy(), m.zero_points.numpy())
+    assert np.allclose(m(x).numpy(), ref, atol=1e-4)

@@ -689,3 +689,43 @@ def test_full_size_linear_b512(fq):
     # fast mode stays inside the north-star bound (<= 1e-3 relative) by a wide margin
     of = ops.linear_forward(x, p, s, z, precision="fast")
     assert rel_fro(of[:16].cpu().numpy(), out[:16].cpu().numpy()) < FAST_REL_FRO
+
+
+# ------------------------------------------------------------------------------ per-group scales along K
+@pytest.mark.parametrize("B,N,K,group", [(1, 64, 256, 64), (7, 200, 512, 128), (40, 96, 1024, 32), (3, 33, 96, 2)])
+def test_per_group_scales_linear(fq, B, N, K, group):
+    """Not in the reference (per-row only): checked against the float64 dequantize-then-matmul with per-group constants."""
+    from fused_int4_amd import ops
+    rng = np.random.default_rng(B + K)
+    w = rng.standard_normal((N, K)).astype(np.float32)
+    p, s, z = O.quantize_weights_grouped(w, group)
+    x = rng.standard_normal((B, K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    got = ops.linear_forward(dev(x), dev(p), dev(s), dev(z)).cpu().numpy()
+    ref = O.reference_linear_grouped(x, p, s, z)
+    assert rel_fro(got, ref) < FMA_REL_FRO
+    gotb = ops.linear_forward(dev(x), dev(p), dev(s), dev(z), bias=dev(bias)).cpu().numpy()
+    assert np.array_equal(gotb, got + bias[None, :])
+    # GPU quantiser + module
+    m = fq.QuantizedLinear.from_linear(torch.nn.Linear(K, N, bias=False), group_size=group).cuda()
+    assert m.scales.shape == (N, K // group)
+    xt = torch.from_numpy(x)
+    assert torch.allclose(m(xt.cuda()).cpu(), m.cpu()(xt), atol=1e-3, rtol=1e-5)
+
+
+def test_per_group_scales_grouped_moe(fq):
+    from fused_int4_amd import ops
+    rng = np.random.default_rng(5)
+    E, N, K, group = 4, 96, 256, 64
+    counts = np.array([9, 0, 17, 5], np.int32)
+    offs = (np.cumsum(counts) - counts).astype(np.int32)
+    T = int(counts.sum()) + 2
+    q = [O.quantize_weights_grouped(rng.standard_normal((N, K)).astype(np.float32), group) for _ in range(E)]
+    P, S, Z = (np.stack([t[i] for t in q]) for i in range(3))
+    x = rng.standard_normal((T, K)).astype(np.float32)
+    out = ops.moe_group_forward(dev(P), dev(S), dev(Z), dev(x), dev(counts), dev(offs)).cpu().numpy()
+    for e in range(E):
+        o, c = int(offs[e]), int(counts[e])
+        if c:
+            assert rel_fro(out[o:o + c], O.reference_linear_grouped(x[o:o + c], P[e], S[e], Z[e])) < FMA_REL_FRO
+    assert (out[T - 2:] == 0).all()
