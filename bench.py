@@ -325,21 +325,15 @@ def main():
         workload = f"QuantizedLinear {K}->{N}, batch {B}"
         parallelism = "replicas only" if world > 1 else "1 GPU"
 
-    # ------------------------------------------------------------------ output check of the call that gets timed
-    if world == 1 and os.environ.get("FQL_BENCH_SKIP_CHECK") != "1":
-        out0 = step()
-        torch.cuda.synchronize()
-        if a.workload == "moe":
-            P0, S0, Z0 = sets[(step_i[0] - 1) % len(sets)]
-            extra["output_check"] = check_outputs(out0, x, P0, S0, Z0, tpe, offs, prec)
-        else:
-            p0, s0, z0 = sets[(step_i[0] - 1) % len(sets)]
-            extra["output_check"] = check_outputs(out0 if out0.dim() == 2 else out0[None], x if x.dim() == 2 else x[None],
-                                                  p0, s0, z0, None, None, prec)
-        extra["max_rel_err"] = extra["output_check"]["max_rel_err"]
-        del out0
-
     # ------------------------------------------------------------------ timed region (the contract)
+    # Before the W warm-up steps: keep the GPU busy with the same call for ~0.25 s.  The workload construction above ends
+    # with host-side work, the device drops into a low-power state meanwhile, and climbing out of it took 30-70 ms on the
+    # MI355X boxes of this pool -- longer than W short steps, so it used to land inside the timed region.
+    t_wake = time.perf_counter()
+    while time.perf_counter() - t_wake < 0.25:
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
     for _ in range(a.warmup):
         step()
     barrier(); torch.cuda.synchronize()
@@ -387,7 +381,7 @@ def main():
     # ------------------------------------------------------------------ per-kernel durations (HIP events on the launch stream)
     roofline = ep_roofline
     if phases is not None and world == 1:
-        n = a.steps
+        n = max(a.steps, 20)
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)]
         outs = torch.empty((rows, N), dtype=torch.float32, device=dev)
         bufs = None
@@ -403,9 +397,15 @@ def main():
         torch.cuda.synchronize()
         pre = sorted(e[0].elapsed_time(e[1]) for e in ev)
         gem = sorted(e[1].elapsed_time(e[2]) for e in ev)
-        gemm_ms = sum(gem) / n
+        # The event pair brackets the launch call, so a preempted host thread (shared box) shows up as GPU idle time inside
+        # the interval: samples above 1.5x the median are host stalls, not kernel time -- they are left out of the
+        # average the roofline uses, and counted.
+        keep = [g for g in gem if g <= 1.5 * gem[n // 2]]
+        gemm_ms = sum(keep) / len(keep)
         extra.update({"gemm_kernel_ms_avg": gemm_ms, "gemm_kernel_ms_median": gem[n // 2], "gemm_kernel_ms_min": gem[0],
-                      "act_quant_ms_avg": sum(pre) / n, "act_quant_ms_median": pre[n // 2]})
+                      "gemm_kernel_ms_avg_all_samples": sum(gem) / n, "gemm_kernel_samples_dropped_as_host_stalls": n - len(keep),
+                      "act_quant_ms_avg": sum(p for p in pre if p <= 1.5 * pre[n // 2]) / max(1, len([p for p in pre if p <= 1.5 * pre[n // 2]])),
+                      "act_quant_ms_median": pre[n // 2]})
         mfma_achieved = flops / (gemm_ms * 1e-3) / 1e12
         hbm_achieved = weight_bytes / (gemm_ms * 1e-3) / 1e9
         mfma_floor_ms = flops * limbs / (MFMA_I8_PEAK_TOPS * 1e12) * 1e3
@@ -502,6 +502,21 @@ def main():
         extra["int8_mode_1_limb"] = {"ms_per_step": ms_i8, "value": flops / (ms_i8 * 1e-3) / 1e12, "unit": "TFLOP/s",
                                      "hbm_GBps_packed_weights_e2e": weight_bytes / (ms_i8 * 1e-3) / 1e9,
                                      "note": "FQL_PRECISION_INT8: 8-bit activations, ~5e-3 relative error (outside the 1e-3 claim); not the headline"}
+
+    # ------------------------------------------------------------------ output check of the timed call (A12 / VERDICT r1)
+    # the same call once more, compared with the oracle on sampled rows of every group; a wrong result fails the run
+    if world == 1 and os.environ.get("FQL_BENCH_SKIP_CHECK") != "1":
+        out0 = step()
+        torch.cuda.synchronize()
+        if a.workload == "moe":
+            P0, S0, Z0 = sets[(step_i[0] - 1) % len(sets)]
+            extra["output_check"] = check_outputs(out0, x, P0, S0, Z0, tpe, offs, prec)
+        else:
+            p0, s0, z0 = sets[(step_i[0] - 1) % len(sets)]
+            extra["output_check"] = check_outputs(out0 if out0.dim() == 2 else out0[None], x if x.dim() == 2 else x[None],
+                                                  p0, s0, z0, None, None, prec)
+        extra["max_rel_err"] = extra["output_check"]["max_rel_err"]
+        del out0
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1 only)
     cpu = None
