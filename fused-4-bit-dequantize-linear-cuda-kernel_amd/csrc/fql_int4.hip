@@ -38,18 +38,40 @@ inline int limbs_of(int precision)
 }
 inline bool is_f8(int precision) { return precision == FQL_PRECISION_FP8; }
 
+// Per-device caches (a process may drive several GPUs): indexed by the current device, idempotent -- a race only repeats
+// the same query / attribute call.
+constexpr int FQL_MAX_DEVICES = 64;
+inline int current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev < FQL_MAX_DEVICES ? dev : FQL_MAX_DEVICES - 1;
+}
+struct PerDeviceFlag {
+    bool set[FQL_MAX_DEVICES] = {};
+};
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and device
+inline bool ensure_lds_attr(PerDeviceFlag &flag, const void *kern, int bytes)
+{
+    const int dev = current_device();
+    if (!flag.set[dev]) {
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+        flag.set[dev] = true;
+    }
+    return true;
+}
 inline int compute_units()
 {
-    static int cached = 0;                                   // idempotent; a race only repeats the query
-    if (cached == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+    static int cached[FQL_MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
             n = 256;                                         // MI355X
         n -= n % 8;                                          // keep vb % 8 == blockIdx % 8 (XCD grouping)
-        cached = n > 0 ? n : 8;
+        cached[dev] = n > 0 ? n : 8;
     }
-    return cached;
+    return cached[dev];
 }
 
 inline int compute_units_hint() { const int n = compute_units(); return n < 256 ? 256 : n; }
@@ -178,6 +200,7 @@ int launch_act_quant(const void *x, int in_dtype, const int32_t *gather, int n_s
     case FQL_DTYPE_BF16: kern = vec ? act_fused_kernel<L, true, 2> : act_fused_kernel<L, false, 2>; break;
     default: kern = vec ? act_fused_kernel<L, true, 0> : act_fused_kernel<L, false, 0>; break;
     }
+    (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3(rblocks + zblocks), dim3(256), 0, st, x, gather, n_src, w.delta, w.rowsum, w.limbs,
                        T, K, Kp / FQL_KB, MBT, rblocks, out, dtype_bytes(out_dtype), N, tpe, offs, E);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
@@ -190,13 +213,9 @@ int launch_gemm_cfg(const Workspace &w, const uint8_t *packed, const float *scal
 {
     using C = GemmCfg<L, WM, WN, NF, DEPTH, BDEPTH>;
     auto kern = gemm_i8_kernel<L, WM, WN, NF, DEPTH, BDEPTH, F8>;
-    static bool attr_set = false;           // idempotent; a race only repeats the same call
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                C::LDS_BYTES) != hipSuccess)
-            return FQL_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static PerDeviceFlag attr;
+    if (!ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), C::LDS_BYTES)) return FQL_ERR_LAUNCH;
+    (void)hipGetLastError();                                 // a stale error of another library must not read as ours
     const int n_tiles = (N + C::BN - 1) / C::BN;
     const int m_slots = (tpe == nullptr) ? (T + C::BM - 1) / C::BM : T / C::BM + E;
     long long blocks = (long long)n_tiles * m_slots;        // worst-case tile count (real count is on the device)
@@ -216,13 +235,9 @@ int launch_rows32_cfg(const Workspace &w, const uint8_t *packed, const float *sc
 {
     using C = Rows32Cfg<L, NF, KG, DEPTH, BDEPTH, OCC>;
     auto kern = gemm_i8_rows32_kernel<L, NF, KG, DEPTH, BDEPTH, OCC>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                C::LDS_BYTES) != hipSuccess)
-            return FQL_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static PerDeviceFlag attr;
+    if (!ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), C::LDS_BYTES)) return FQL_ERR_LAUNCH;
+    (void)hipGetLastError();                                 // a stale error of another library must not read as ours
     const int n_tiles = (N + C::BN - 1) / C::BN;
     const int m_slots = (tpe == nullptr) ? (T + C::BM - 1) / C::BM : T / C::BM + E;
     long long blocks = (long long)n_tiles * m_slots;
@@ -241,13 +256,9 @@ int launch_rows16_cfg(const Workspace &w, const uint8_t *packed, const float *sc
 {
     using C = Rows16Cfg<L, NF, KG, BDEPTH>;
     auto kern = gemm_i8_rows16_kernel<L, NF, KG, BDEPTH>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                C::LDS_BYTES) != hipSuccess)
-            return FQL_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static PerDeviceFlag attr;
+    if (!ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), C::LDS_BYTES)) return FQL_ERR_LAUNCH;
+    (void)hipGetLastError();                                 // a stale error of another library must not read as ours
     const int n_tiles = (N + C::BN - 1) / C::BN;
     const int m_slots = (tpe == nullptr) ? (T + C::BM - 1) / C::BM : T / C::BM + E;
     long long blocks = (long long)n_tiles * m_slots;
@@ -729,14 +740,11 @@ int fql_route_plan_i32(const int32_t *expert_of_slot, int n_slots, int top_k, in
     if (!counts || !offsets) return FQL_ERR_NULL_POINTER;
     if (n_slots > 0 && (!expert_of_slot || !token_of_sorted || !pos_of_slot)) return FQL_ERR_NULL_POINTER;
     const size_t lds = (size_t)(ROUTE_THREADS * E + E) * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(route_plan_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (ROUTE_THREADS * ROUTE_MAX_EXPERTS + ROUTE_MAX_EXPERTS) * (int)sizeof(int)) != hipSuccess)
-            return FQL_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static PerDeviceFlag attr;
+    if (!ensure_lds_attr(attr, reinterpret_cast<const void *>(route_plan_kernel),
+                         (ROUTE_THREADS * ROUTE_MAX_EXPERTS + ROUTE_MAX_EXPERTS) * (int)sizeof(int)))
+        return FQL_ERR_LAUNCH;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(route_plan_kernel, dim3(1), dim3(ROUTE_THREADS), lds, static_cast<hipStream_t>(stream),
                        expert_of_slot, n_slots, top_k, E, counts, offsets, token_of_sorted, pos_of_slot);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;

@@ -142,7 +142,7 @@ class QuantizedMoE(nn.Module):
         return moe
 
     def _stack(self, device):
-        key = tuple((e.packed_weights.data_ptr(), e.packed_weights._version) for e in self.experts)
+        key = tuple((t.data_ptr(), t._version) for e in self.experts for t in (e.packed_weights, e.scales, e.zero_points))
         if self._stacked is None or self._stacked[0] != key or self._stacked[1].device != device:
             packed = torch.stack([e.packed_weights for e in self.experts]).to(device)
             scales = torch.stack([e.scales for e in self.experts]).to(device)

@@ -189,8 +189,11 @@ def moe_forward(packed_weights, scales, zero_points, inputs, expert_ids, tokens_
     if tokens_per_expert.numel() != E or input_offsets.numel() != E:
         raise RuntimeError("tokens_per_expert and input_offsets must have num_experts elements")
     dev = inputs.device
-    tpe = tokens_per_expert.to(torch.int32).contiguous()
-    offs = input_offsets.to(torch.int32).contiguous()
+    for t in (packed_weights, scales, zero_points, tokens_per_expert, input_offsets):
+        if t.device != dev:
+            raise RuntimeError("all tensors must be on the same device")
+    tpe = tokens_per_expert.to(device=dev, dtype=torch.int32).contiguous()
+    offs = input_offsets.to(device=dev, dtype=torch.int32).contiguous()
     packed_weights = packed_weights.contiguous()
     inputs = inputs.contiguous()
     scales = scales.contiguous()
@@ -288,6 +291,23 @@ def moe_forward_any(packed_weights, scales, zero_points, inputs, expert_ids, tok
     return out
 
 
+def _check_grouped_weights(packed_weights, scales, zero_points, dev, K):
+    """Shape / dtype / device checks shared by the grouped wrappers: a wrong-shaped or foreign-device tensor must become a
+    Python error here, not an out-of-bounds read inside a kernel."""
+    if not packed_weights.is_cuda or packed_weights.dtype != torch.uint8 or packed_weights.dim() != 3:
+        raise RuntimeError("packed_weights must be a CUDA uint8 [num_experts, ffn_dim, hidden_dim/2] tensor")
+    E, N, packed_dim = packed_weights.shape
+    if packed_dim * 2 != K:
+        raise RuntimeError("packed_weights dim 2 must be hidden_dim / 2")
+    for name, t in (("scales", scales), ("zero_points", zero_points)):
+        if not t.is_cuda or t.dtype != torch.float32 or tuple(t.shape) != (E, N):
+            raise RuntimeError(f"{name} must be a CUDA float32 [num_experts, ffn_dim] tensor")
+    for t in (packed_weights, scales, zero_points):
+        if t.device != dev:
+            raise RuntimeError("all tensors must be on the same device")
+    return E, N
+
+
 def moe_gather_forward(packed_weights, scales, zero_points, tokens, row_index, tokens_per_expert,
                        input_offsets, precision="default"):
     """Grouped per-expert INT4 GEMM with the dispatch gather fused in: grouped row t = tokens[row_index[t]].
@@ -301,15 +321,17 @@ def moe_gather_forward(packed_weights, scales, zero_points, tokens, row_index, t
             raise RuntimeError(f"{name} must be a CUDA tensor")
     if tokens.dtype != torch.float32 or tokens.dim() != 2:
         raise RuntimeError("tokens must be float32 [n_tokens, hidden_dim]")
-    E, N, packed_dim = packed_weights.shape
     n_tokens, K = tokens.shape
-    if K % 32 != 0 or packed_dim != K // 2:
-        raise RuntimeError("fused gather needs hidden_dim % 32 == 0 and packed_weights dim 2 == hidden_dim / 2")
-    T = row_index.numel()
     dev = tokens.device
-    ri = row_index.to(torch.int32).contiguous()
-    tpe = tokens_per_expert.to(torch.int32).contiguous()
-    offs = input_offsets.to(torch.int32).contiguous()
+    E, N = _check_grouped_weights(packed_weights, scales, zero_points, dev, K)
+    if K % 32 != 0:
+        raise RuntimeError("fused gather needs hidden_dim % 32 == 0")
+    if tokens_per_expert.numel() != E or input_offsets.numel() != E:
+        raise RuntimeError("tokens_per_expert and input_offsets must have num_experts elements")
+    T = row_index.numel()
+    ri = row_index.to(device=dev, dtype=torch.int32).contiguous()
+    tpe = tokens_per_expert.to(device=dev, dtype=torch.int32).contiguous()
+    offs = input_offsets.to(device=dev, dtype=torch.int32).contiguous()
     tokens = tokens.contiguous()
     L = _native.lib()
     prec = _precision(precision)
@@ -331,12 +353,14 @@ def moe_gated_forward(packed_weights, scales, zero_points, gate_up, tokens_per_e
     fused gate|up projection), ``packed_weights`` [E, N, K/2].  The [T, K] hidden activation is never written."""
     if not gate_up.is_cuda or gate_up.dtype != torch.float32 or gate_up.dim() != 2:
         raise RuntimeError("gate_up must be a CUDA float32 [T, 2K] tensor")
-    E, N, packed_dim = packed_weights.shape
     T, K2 = gate_up.shape
     K = K2 // 2
-    if K2 % 2 or packed_dim * 2 != K or K % 32:
-        raise RuntimeError("gate_up must be [T, 2K] with K = 2 * packed_weights.shape[2] and K % 32 == 0")
     dev = gate_up.device
+    if K2 % 2 or K % 32:
+        raise RuntimeError("gate_up must be [T, 2K] with K % 32 == 0")
+    E, N = _check_grouped_weights(packed_weights, scales, zero_points, dev, K)
+    if tokens_per_expert.numel() != E or input_offsets.numel() != E:
+        raise RuntimeError("tokens_per_expert and input_offsets must have num_experts elements")
     gate_up = gate_up.contiguous()
     tpe = tokens_per_expert.to(device=dev, dtype=torch.int32).contiguous()
     offs = input_offsets.to(device=dev, dtype=torch.int32).contiguous()
