@@ -479,8 +479,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
 #pragma unroll
         for (int l = 0; l < L; ++l) rs[l] = (float)rsi[l];
         const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & (out_kind == 0 ? 15 : 7)) == 0);
+        // (the lane part goes through an opaque register: otherwise the compiler hoists all NF * 4 slot pointers out of
+        //  the persistent tile loop, keeps them live across the K loop and spills them -- 72 bytes of scratch per lane)
+        int lane4 = lane * 4;
+        asm volatile("" : "+v"(lane4));
         float *slot0 = (MODE == 0) ? nullptr
-                                   : res_scratch + ((size_t)blockIdx.x * C::NW + wave) * (NF * 1024) + lane * 4;
+                                   : res_scratch + ((size_t)blockIdx.x * C::NW + wave) * (NF * 1024) + lane4;
 #pragma unroll
         for (int j = 0; j < NF; ++j)
 #pragma unroll
