@@ -156,7 +156,7 @@ __device__ __forceinline__ int act_token_rows(int p0, int rows, int *s_tok, ActL
 // split into int8 limbs -- the "fp8 activations" mode (FQL_PRECISION_FP8, BASELINE.json configs[4]).  delta[t] is the
 // float32 quotient max|x| / 448, the stored byte the conversion of the float32 quotient x / delta[t]; rowsum[0][t]
 // holds sum_k of the ROUNDED values as float32 bits (summed exactly as integers in units of 2^-9).
-template <int L, bool VEC, int IN, bool GATE = false, bool F8OUT = false>
+template <int L, bool VEC, int IN, bool GATE = false, bool F8OUT = false, int AR = ACT_ROWS>
 __global__ __launch_bounds__(256) void act_fused_kernel(
     const void *__restrict__ xin, const int32_t *__restrict__ gather, int n_src, float *__restrict__ delta,
     int32_t *__restrict__ rowsum, int8_t *__restrict__ limbs, int T, int K, int KB, int MBT, int rblocks,
@@ -164,12 +164,17 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
     int E)
 {
     constexpr int ES = (IN == 0) ? 4 : 2;         // bytes per element of x
-    __shared__ int s_tok[ACT_ROWS];
-    __shared__ uint32_t s_max[4][ACT_ROWS];
-    __shared__ int s_sum[4][ACT_ROWS][L];
-    __shared__ long long s_sum8[4][ACT_ROWS];
-    __shared__ float s_ssq[4][ACT_ROWS];
-    __shared__ int s_flag[ACT_ROWS];
+    // AR rows per workgroup: 4 at throughput sizes (measured best at configs[2]); 1 when there are only a few rows in
+    // all (decode / small-batch linear), where the pre-pass is a latency chain and a row spread over 256 threads
+    // (16 values each) shortens every link of it
+    constexpr int R_ = AR, COLS_ = 256 / AR, CH_ = 256 / COLS_;
+    static_assert(AR == 1 || AR == 2 || AR == 4 || AR == 8, "rows per workgroup");
+    __shared__ int s_tok[R_];
+    __shared__ uint32_t s_max[4][R_];
+    __shared__ int s_sum[4][R_][L];
+    __shared__ long long s_sum8[4][R_];
+    __shared__ float s_ssq[4][R_];
+    __shared__ int s_flag[R_];
     __shared__ ActLookupShared s_lookup;
     static_assert(!F8OUT || L == 1, "fp8 activations are one byte plane");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -180,29 +185,29 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
     }
 
     // ---- token row of each of the workgroup's padded rows (-1: padding); total = padded rows in use
-    const int p0 = blockIdx.x * ACT_ROWS;
-    const int total = act_token_rows(p0, ACT_ROWS, s_tok, s_lookup, tpe, offs, E, T);
+    const int p0 = blockIdx.x * R_;
+    const int total = act_token_rows(p0, R_, s_tok, s_lookup, tpe, offs, E, T);
     if (p0 >= total) return;                      // past the last expert's rows (uniform per workgroup)
     __syncthreads();
 
-    const int r = tid & (ACT_ROWS - 1), col = tid / ACT_ROWS;   // row of the workgroup, chunk column
+    const int r = tid & (R_ - 1), col = tid / R_;   // row of the workgroup, chunk column
     const int tok = s_tok[r];
     const int p = p0 + r, mb = p >> 5, r32 = p & 31;
     static_assert(!GATE || IN == 0, "the gated pre-pass takes float32 rows");
     const char *xr = reinterpret_cast<const char *>(xin) +
                      (size_t)(tok >= 0 ? source_row(gather, n_src, tok) : 0) * K * ES * (GATE ? 2 : 1);
     const int nch = KB * 16;                      // 16-float chunks per padded row
-    const int slabs = (nch + ACT_COLS * ACT_CH - 1) / (ACT_COLS * ACT_CH);
+    const int slabs = (nch + COLS_ * CH_ - 1) / (COLS_ * CH_);
 
     // VEC (K % 16 == 0, x 16-byte aligned; host-checked): every load is unconditional.  A chunk past K (the
     // zero padding up to a multiple of 256) or a padding row re-reads valid data -- duplicates do not move the
     // row max -- and is masked to +0.0f in pass 2.
-    v4f xv[ACT_CH][4];
-    auto chunk_ok = [&](int slab, int j) { return tok >= 0 && (slab * ACT_COLS * ACT_CH + col + ACT_COLS * j) * 16 < K; };
+    v4f xv[CH_][4];
+    auto chunk_ok = [&](int slab, int j) { return tok >= 0 && (slab * COLS_ * CH_ + col + COLS_ * j) * 16 < K; };
     auto load_slab = [&](int slab) {
 #pragma unroll
-        for (int j = 0; j < ACT_CH; ++j) {
-            const int k0 = (slab * ACT_COLS * ACT_CH + col + ACT_COLS * j) * 16;
+        for (int j = 0; j < CH_; ++j) {
+            const int k0 = (slab * COLS_ * CH_ + col + COLS_ * j) * 16;
             if (VEC) {
                 const char *src = xr + (size_t)(k0 < K ? k0 : 0) * ES;
                 if (IN == 0 && GATE) {
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
     for (int slab = 0; slab < slabs; ++slab) {
         load_slab(slab);
 #pragma unroll
-        for (int j = 0; j < ACT_CH; ++j)
+        for (int j = 0; j < CH_; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -261,11 +266,11 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
                 }
     }
 #pragma unroll
-    for (int o = ACT_ROWS; o < 64; o <<= 1) {
+    for (int o = R_; o < 64; o <<= 1) {
         const uint32_t n = (uint32_t)__shfl_xor((int)mu, o, 64);
         mu = n > mu ? n : mu;
     }
-    if (lane < ACT_ROWS) s_max[wave][lane] = mu;
+    if (lane < R_) s_max[wave][lane] = mu;
     __syncthreads();
     {
         const uint32_t a = s_max[0][r] > s_max[1][r] ? s_max[0][r] : s_max[1][r];
@@ -277,13 +282,13 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
     if constexpr (F8OUT) {
         // ---- pass 2 (fp8): y = x / scale rounded to e4m3, scale = max|x| / 448 (1 for an all-zero row)
         const float scale = (bad || m == 0.0f) ? 1.0f : m / 448.0f;
-        if (tid < ACT_ROWS && tok >= 0) delta[tok] = bad ? __builtin_nanf("") : scale;
+        if (tid < R_ && tok >= 0) delta[tok] = bad ? __builtin_nanf("") : scale;
         long long sum8 = 0;
         for (int slab = 0; slab < slabs; ++slab) {
             if (slabs > 1) load_slab(slab);
 #pragma unroll
-            for (int j = 0; j < ACT_CH; ++j) {
-                const int ch = slab * ACT_COLS * ACT_CH + col + ACT_COLS * j;
+            for (int j = 0; j < CH_; ++j) {
+                const int ch = slab * COLS_ * CH_ + col + COLS_ * j;
                 if (ch >= nch) continue;
                 const uint32_t keep = (chunk_ok(slab, j) && !bad) ? 0xFFFFFFFFu : 0u;
                 uint32_t nat[4];                               // e4m3 bytes of k = 4 dw .. 4 dw + 3, natural order
@@ -310,10 +315,10 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
             }
         }
 #pragma unroll
-        for (int o = ACT_ROWS; o < 64; o <<= 1) sum8 += __shfl_xor(sum8, o, 64);
-        if (lane < ACT_ROWS) s_sum8[wave][lane] = sum8;
+        for (int o = R_; o < 64; o <<= 1) sum8 += __shfl_xor(sum8, o, 64);
+        if (lane < R_) s_sum8[wave][lane] = sum8;
         __syncthreads();
-        if (tid < ACT_ROWS && tok >= 0) {
+        if (tid < R_ && tok >= 0) {
             const long long tot = (s_sum8[0][tid] + s_sum8[1][tid]) + (s_sum8[2][tid] + s_sum8[3][tid]);
             rowsum[tok] = __float_as_int((float)tot * 0x1p-9f);
         }
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
     }
     const int e = act_exponent<L>(bad ? 0.0f : m);
     const float inv = bad ? 0.0f : ldexpf(1.0f, -e);           // non-finite row: limbs 0, delta NaN -> outputs NaN
-    if (tid < ACT_ROWS && tok >= 0) delta[tok] = bad ? __builtin_nanf("") : ldexpf(1.0f, e);
+    if (tid < R_ && tok >= 0) delta[tok] = bad ? __builtin_nanf("") : ldexpf(1.0f, e);
 
     // ---- pass 2: quantise and store.  Pass 3 (rows flagged as heavy-tailed only, L >= 2): the RESIDUAL of pass 2's
     //      rounding, r = x / delta - X in [-1/2, 1/2] (exact in float32), as a second fixed-point value
@@ -340,8 +345,8 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
         for (int slab = 0; slab < slabs; ++slab) {
             if (slabs > 1) load_slab(slab);
 #pragma unroll
-            for (int j = 0; j < ACT_CH; ++j) {
-                const int ch = slab * ACT_COLS * ACT_CH + col + ACT_COLS * j;
+            for (int j = 0; j < CH_; ++j) {
+                const int ch = slab * COLS_ * CH_ + col + COLS_ * j;
                 if (ch >= nch) continue;
                 // All L balanced digits of X at once: Y = X + sum_{l<L-1} 128*256^l has plain base-256 digits
                 // d_l + 128 in its low bytes and the top digit above them, so byte l of Z = Y ^ 0x..8080 is limb l.
@@ -395,8 +400,8 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
 #pragma unroll
         for (int l = 0; l < L; ++l) {
 #pragma unroll
-            for (int o = ACT_ROWS; o < 64; o <<= 1) sums[l] += __shfl_xor(sums[l], o, 64);
-            if (lane < ACT_ROWS) s_sum[wave][lane][l] = sums[l];
+            for (int o = R_; o < 64; o <<= 1) sums[l] += __shfl_xor(sums[l], o, 64);
+            if (lane < R_) s_sum[wave][lane][l] = sums[l];
         }
     };
     int sums[L];
@@ -407,11 +412,11 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
     reduce_sums(sums);
     if (RES) {
 #pragma unroll
-        for (int o = ACT_ROWS; o < 64; o <<= 1) ssq += __shfl_xor(ssq, o, 64);
-        if (lane < ACT_ROWS) s_ssq[wave][lane] = ssq;
+        for (int o = R_; o < 64; o <<= 1) ssq += __shfl_xor(ssq, o, 64);
+        if (lane < R_) s_ssq[wave][lane] = ssq;
     }
     __syncthreads();
-    if (tid < ACT_ROWS) {
+    if (tid < R_) {
         int flag = 0;
         if (tok >= 0) {
 #pragma unroll
@@ -428,14 +433,18 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
     }
     if (!RES) return;
     __syncthreads();
-    if ((s_flag[0] | s_flag[1] | s_flag[2] | s_flag[3]) == 0) return;       // ACT_ROWS == 4 (static_assert below)
-    static_assert(ACT_ROWS == 4, "the heavy-tail flags of a workgroup are read as four words");
+    {
+        int any = 0;
+#pragma unroll
+        for (int i = 0; i < R_; ++i) any |= s_flag[i];
+        if (any == 0) return;
+    }
 #pragma unroll
     for (int l = 0; l < L; ++l) sums[l] = 0;
     emit(std::true_type{}, sums, ssq, s_flag[r] != 0);
     reduce_sums(sums);
     __syncthreads();
-    if (tid < ACT_ROWS && tok >= 0 && s_flag[tid]) {
+    if (tid < R_ && tok >= 0 && s_flag[tid]) {
 #pragma unroll
         for (int l = 0; l < L; ++l)
             rowsum[(size_t)(L + l) * T + tok] = (s_sum[0][tid][l] + s_sum[1][tid][l]) + (s_sum[2][tid][l] + s_sum[3][tid][l]);

@@ -38,9 +38,13 @@ struct Rows16Cfg {
     static constexpr int PIECES = NF * 2;                     // 1 KiB weight pieces (8 rows x 128 B) per wave per stage
     static constexpr int SLAB = NF * 16 * (FQL_KB / 2);       // wave-private LDS bytes: one stage of packed weights
     static constexpr int ACC_BYTES = L * NF * 4 * 64 * 4;
-    static constexpr int RED_BYTES = (KG > 1) ? (KG / 2) * NG * ACC_BYTES : 0;
-    static constexpr int MAIN_BYTES = (NW * SLAB > RED_BYTES) ? NW * SLAB : RED_BYTES;
     static constexpr int SZ_BYTES = 2 * 3 * BN * 4;           // scale / zero-point / bias slices of two tiles
+    // K-group partial sums: FLAT = every wave parks its accumulators once and fragment j of a column group is summed
+    // and finished (epilogue, store) by the wave with kg = j % KG -- one exchange instead of a log2(KG)-round tree
+    // and the epilogue spread over the K groups; the tree remains for shapes whose partials do not fit in LDS
+    static constexpr bool FLAT = (KG > 1) && (NW * ACC_BYTES + SZ_BYTES <= 160 * 1024);
+    static constexpr int RED_BYTES = (KG > 1) ? (FLAT ? NW * ACC_BYTES : (KG / 2) * NG * ACC_BYTES) : 0;
+    static constexpr int MAIN_BYTES = (NW * SLAB > RED_BYTES) ? NW * SLAB : RED_BYTES;
     static constexpr int LDS_BYTES = MAIN_BYTES + SZ_BYTES;
     static constexpr int SZN = (3 * BN + THREADS - 1) / THREADS;
     static_assert(KG == 1 || KG == 2 || KG == 4 || KG == 8, "K split");
@@ -228,13 +232,33 @@ const __amdgpu_buffer_rsrc_t rsBi = __builtin_amdgcn_make_buffer_rsrc(
     int ev = 0;
     FQL_STAMP(ev++);                                           // kernel entry
     GemmTile cur = tile_params(blockIdx.x);
-    if constexpr (RES) cur.rp = tile_has_residual(delta, T, cur, C::BM, lane) && res_scratch != nullptr;
     {
+        // first tile: every load goes out at once -- weights, the activations of the MAIN pass and the tile constants;
+        // the heavy-tail answer for the tile's rows is read meanwhile through the SCALAR cache (uniform addresses, its
+        // own counter: it does not queue behind the weight stream the way a vector load would), and only a tile that
+        // does have such rows re-issues its activations and constants for the residual pass
         const __amdgpu_buffer_rsrc_t rs = w_rsrc(cur);
-        issue_acts(a_soff(cur, 0), 0);
-        issue_tile_consts(cur);
 #pragma unroll
         for (int u = 0; u < BD; ++u) issue_weights(rs, w_soff(cur, u), u);
+        issue_acts(a_soff(cur, 0), 0);
+        issue_tile_consts(cur);
+        if constexpr (RES) {
+            if (res_scratch != nullptr && cur.ok) {
+                const uint32_t *d2 = reinterpret_cast<const uint32_t *>(delta) + T + cur.row0;
+                const int last = cur.rows_valid - 1;
+                uint32_t v[C::BM];
+#pragma unroll
+                for (int i = 0; i < C::BM; ++i) v[i] = d2[i < last ? i : last];
+                uint32_t any = 0;
+#pragma unroll
+                for (int i = 0; i < C::BM; ++i) any |= v[i];
+                cur.rp = __builtin_amdgcn_readfirstlane((any & 0x7fffffffu) != 0 ? 1 : 0);
+                if (cur.rp) {
+                    issue_acts(a_soff(cur, 0), 0);
+                    issue_tile_consts(cur);
+                }
+            }
+        }
     }
     int parity = 0;                                            // tile parity (scale slice buffer)
 
@@ -310,8 +334,29 @@ const __amdgpu_buffer_rsrc_t rsBi = __builtin_amdgcn_make_buffer_rsrc(
     }
 
     FQL_STAMP(ev++);                                           // K loop done
-    // ---- add the KG partial accumulators through LDS, pairwise (int32: exact, order-free)
-    if (KG > 1) {
+    // ---- add the KG partial accumulators through LDS (int32: exact, order-free)
+    if constexpr (C::FLAT) {
+        __syncthreads();                                       // every wave is done with its weight slab
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+                *reinterpret_cast<v4i *>(lds + wave * C::ACC_BYTES + ((l * NF + j) * 64 + lane) * 16) = acc[l][j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            if (j % KG != kg) continue;                        // fragment j belongs to the wave with kg = j % KG
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                v4i tot = v4i{0, 0, 0, 0};
+#pragma unroll
+                for (int g2 = 0; g2 < KG; ++g2)
+                    tot += *reinterpret_cast<const v4i *>(lds + (g2 * NG + ng) * C::ACC_BYTES + ((l * NF + j) * 64 + lane) * 16);
+                acc[l][j] = tot;
+            }
+        }
+        __syncthreads();                                       // the slabs are free again for the next tile's weights
+    } else if (KG > 1) {
 #pragma unroll
         for (int sft = 1; sft < KG; sft <<= 1) {
             char *red = lds + ((kg / (2 * sft)) * NG + ng) * C::ACC_BYTES;
@@ -345,7 +390,7 @@ const __amdgpu_buffer_rsrc_t rsBi = __builtin_amdgcn_make_buffer_rsrc(
     FQL_STAMP(ev++);                                           // reduction done
     const GemmTile done = cur;
     cur = nxt;
-    if (kg != 0 || !done.ok || l15 >= done.rows_valid) continue;
+    if ((!C::FLAT && kg != 0) || !done.ok || l15 >= done.rows_valid) continue;
     const int t = done.row0 + l15;
     const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & (out_kind == 0 ? 15 : 7)) == 0);
     // MODE 0 plain tile / 1 residual pass (park float32 results in the scratch slot) / 2 main pass after it (add them)
@@ -354,6 +399,7 @@ const __amdgpu_buffer_rsrc_t rsBi = __builtin_amdgcn_make_buffer_rsrc(
         float *slot0 = (MODE == 0) ? nullptr : res_scratch + ((size_t)blockIdx.x * C::NW + wave) * (NF * 256) + lane * 4;
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
+            if (C::FLAT && j % KG != kg) continue;              // finished by the wave that summed it
             const int c0 = (ng * NF + j) * 16 + 4 * kq;           // column inside the tile
             const v4f s4 = *reinterpret_cast<const v4f *>(sz + c0);
             const v4f z4 = *reinterpret_cast<const v4f *>(sz + C::BN + c0);

@@ -17,9 +17,9 @@
 namespace {
 
 // Batches up to this many rows take the float32 GEMV kernel, larger ones the MFMA path (measured on MI355X, 4096 -> 11008,
-// product call in a hipGraph: GEMV 9.4 / 12.0 / 19.3 / 23.0 us at B = 1 / 2 / 3 / 4, MFMA path 19.2 / 19.9 / 20.2 us at
-// B = 2 / 3 / 4 and 20.4 us at B = 5..16: profiles/r02_linear_batch_sweep.txt).  Tuning hook below.
-int g_gemv_max_rows = 3;
+// product call in a hipGraph: GEMV 9.3 / 12.1 / 19.7 us at B = 1 / 2 / 3, MFMA path 16.4 / 16.5 / 16.1 us at
+// B = 2 / 3 / 4 and 16.2-16.5 us at B = 5..16: profiles/r02_linear_batch_sweep.txt).  Tuning hook below.
+int g_gemv_max_rows = 2;
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline size_t round16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -152,8 +152,12 @@ constexpr int FQL_NUM_ROWS32 = 8;
     S(1, 4, 2, 2)              /* 16 x 256 */ \
     S(2, 4, 4, 1)              /* 16 x 128, one weight stage in flight */ \
     S(3, 4, 8, 1)              /* 16 x  64 */ \
-    S(4, 8, 4, 1)              /* 16 x 256, 8 fragments per wave */
-constexpr int FQL_NUM_ROWS16 = 5;
+    S(4, 8, 4, 1)              /* 16 x 256, 8 fragments per wave */ \
+    S(5, 4, 8, 2)              /* 16 x  64, both weight stages of a 4096-k row in flight from the start */ \
+    S(6, 3, 8, 2)              /* 16 x  48 */ \
+    S(7, 3, 8, 1)              /* 16 x  48, one weight stage in flight */ \
+    S(8, 2, 8, 2)              /* 16 x  32 */
+constexpr int FQL_NUM_ROWS16 = 9;
 inline bool valid_cfg(int cfg) { return (cfg >= 0 && cfg < FQL_NUM_CFG) || (cfg >= 100 && cfg < 100 + FQL_NUM_ROWS32) ||
            (cfg >= 200 && cfg < 200 + FQL_NUM_ROWS16);
 }
@@ -181,25 +185,31 @@ int launch_act_quant(const void *x, int in_dtype, const int32_t *gather, int n_s
     // 8-row workgroups over the padded rows that can hold real rows (every expert's rows rounded up to 32), plus
     // (MoE entry point) the workgroups that zero the rows of `out` no expert covers
     const int mblocks = (tpe == nullptr) ? (T + FQL_MB - 1) / FQL_MB : (T + FQL_MB * E) / FQL_MB;
-    const int rblocks = mblocks * (FQL_MB / ACT_ROWS);
-    const int zblocks = (tpe != nullptr && out != nullptr) ? (T + 255) / 256 : 0;
     const bool vec = (K % 16 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+    // few rows in all (at most four single-row workgroups per CU): one row per workgroup -- the pre-pass is a latency
+    // chain there and a row spread over 256 threads shortens every link of it (fql_act_quant.h)
+    const bool single = vec && mblocks * FQL_MB <= 1024;
+    const int rblocks = mblocks * (single ? FQL_MB : FQL_MB / ACT_ROWS);
+    const int zblocks = (tpe != nullptr && out != nullptr) ? (T + 255) / 256 : 0;
     void (*kern)(const void *, const int32_t *, int, float *, int32_t *, int8_t *, int, int, int, int, int, void *, int,
                  int, const int32_t *, const int32_t *, int);
+#define FQL_ACT_PICK(l, in, gate, f8) \
+    (single ? act_fused_kernel<l, true, in, gate, f8, 1> : (vec ? act_fused_kernel<l, true, in, gate, f8> : act_fused_kernel<l, false, in, gate, f8>))
     if (f8out) {
         if constexpr (L == 1) {
             switch (in_dtype) {
-            case FQL_DTYPE_F16: kern = vec ? act_fused_kernel<1, true, 1, false, true> : act_fused_kernel<1, false, 1, false, true>; break;
-            case FQL_DTYPE_BF16: kern = vec ? act_fused_kernel<1, true, 2, false, true> : act_fused_kernel<1, false, 2, false, true>; break;
-            default: kern = vec ? act_fused_kernel<1, true, 0, false, true> : act_fused_kernel<1, false, 0, false, true>; break;
+            case FQL_DTYPE_F16: kern = FQL_ACT_PICK(1, 1, false, true); break;
+            case FQL_DTYPE_BF16: kern = FQL_ACT_PICK(1, 2, false, true); break;
+            default: kern = FQL_ACT_PICK(1, 0, false, true); break;
             }
         } else return FQL_ERR_BAD_PRECISION;
-    } else if (gated) kern = vec ? act_fused_kernel<L, true, 0, true> : act_fused_kernel<L, false, 0, true>;
+    } else if (gated) kern = FQL_ACT_PICK(L, 0, true, false);
     else switch (in_dtype) {
-    case FQL_DTYPE_F16: kern = vec ? act_fused_kernel<L, true, 1> : act_fused_kernel<L, false, 1>; break;
-    case FQL_DTYPE_BF16: kern = vec ? act_fused_kernel<L, true, 2> : act_fused_kernel<L, false, 2>; break;
-    default: kern = vec ? act_fused_kernel<L, true, 0> : act_fused_kernel<L, false, 0>; break;
+    case FQL_DTYPE_F16: kern = FQL_ACT_PICK(L, 1, false, false); break;
+    case FQL_DTYPE_BF16: kern = FQL_ACT_PICK(L, 2, false, false); break;
+    default: kern = FQL_ACT_PICK(L, 0, false, false); break;
     }
+#undef FQL_ACT_PICK
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3(rblocks + zblocks), dim3(256), 0, st, x, gather, n_src, w.delta, w.rowsum, w.limbs,
                        T, K, Kp / FQL_KB, MBT, rblocks, out, dtype_bytes(out_dtype), N, tpe, offs, E);
@@ -350,7 +360,7 @@ inline int choose_cfg(int L, int E, int T, int K, int N, bool grouped)
     // weights (N / 64 tiles per row block instead of N / 256)
     const long long wide_tiles = (long long)groups * ((m + 127) / 128) * ((N + 255) / 256);
     if (wide_tiles < 128 && m <= 128) {
-        if (m <= 16) return 203;                             //  16 x 64 decode tiles, K split 8 ways (fql_gemm_rows16.h)
+        if (m <= 16) return 207;                             //  16 x 48 decode tiles, K split 8 ways (fql_gemm_rows16.h)
         if (m <= 32) return 8;                               //  32 x 64, 2 waves
         if (m <= 64) return 7;                               //  64 x 64, 4 waves
         return 13;                                           // 128 x 64, 4 waves, 8 weight stages in flight

@@ -99,7 +99,7 @@ FQL_API const char *fql_error_string(int code);
  *   scales  [N] float32,  zps [N] float32
  *   out     [B][N] float32, contiguous, fully overwritten
  *   workspace: fql_linear_workspace_bytes(B, K, N, precision) bytes, 16-byte aligned
- *              (0 bytes are needed for B <= 4: pass NULL)
+ *              (0 bytes are needed for B <= 2; B = 3, 4 also run with NULL, on the slower GEMV kernel)
  * Any even K is accepted; K % 32 == 0 with 16-byte aligned `packed` takes the fast paths.
  * ------------------------------------------------------------------------------------- */
 FQL_API size_t fql_linear_workspace_bytes(int B, int K, int N, int precision);
