@@ -303,7 +303,10 @@ def main():
         parallelism = f"ep{world}"
     else:
         B = 512 if a.workload == "linear512" else 1
-        sets = [tuple(t[0] for t in make_weights(1, N, K, dev, 42 + i)) for i in range(max(1, a.weight_sets))]
+        # one weight set is 22.5 MB: rotate through enough of them (3 x the 256 MB Infinity Cache) that a step can
+        # find none of its weights in a cache, unless warm numbers were asked for (--weight-sets 1)
+        n_sets = 1 if a.weight_sets == 1 else max(a.weight_sets, -(-3 * 256 * 2**20 // (N * (K // 2))))
+        sets = [tuple(t[0] for t in make_weights(1, N, K, dev, 42 + i)) for i in range(n_sets)]
         torch.manual_seed(42)
         x = torch.randn(B, K, device=dev)
         rows = B
