@@ -65,6 +65,8 @@ __device__ unsigned long long fql_trace_wide[8 * 64];
 
 struct GemmTile {              // wave-uniform description of one visit of a BM x BN tile
     int e, row0, prow0, rows_valid, nt, ok;
+    int n0, nfr;               // wide kernel: first column and 32-column fragments of this tile (tiles of one row block
+                               // differ by at most one fragment: see tile_params)
     int rp;                    // this visit is the RESIDUAL pass of a tile with heavy-tailed rows (its main pass follows)
     int ad;                    // this visit is the main pass that follows a residual pass: add the parked partial results
 };
@@ -114,8 +116,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     const int32_t *__restrict__ rowsum, const uint8_t *__restrict__ packed,
     const float *__restrict__ scales, const float *__restrict__ zps, void *__restrict__ out, int out_kind,
     const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
-    int E, int T, int K, int Kp, int MBT, int N, int n_tiles, int m_slots, float *__restrict__ res_scratch,
-    const float *__restrict__ bias)
+    int E, int T, int K, int Kp, int MBT, int N, int n_tiles_min, int m_slots, float *__restrict__ res_scratch,
+    const float *__restrict__ bias, int n_tiles_alt)
 {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub
     using C = GemmCfg<L, WM, WN, NF, DEPTH, BDEPTH>;
@@ -136,17 +138,44 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave - wm * WN;
+    // wave w runs on SIMD w % 4: the two waves of a SIMD are the two COLUMN halves of one 32-row block (same wm, wn = 0 / 1),
+    // so a tile that is one fragment narrower (below) takes that fragment's MFMAs off every SIMD alike
+    const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, g = lane >> 5;
+    int n_tiles = n_tiles_min;
     int n_real = m_slots * n_tiles;
+    // ---- columns: the N / 32 fragments of a row block are dealt to its n_tiles tiles as evenly as possible, the wider
+    //      tiles first: tile i holds base + (i < rem) fragments.  With the fewest tiles that cover N this is the plain
+    //      BN-wide tiling; the host may ask for more, narrower tiles so that the tiles every persistent workgroup walks
+    //      add up alike (8 x 128 rows x 11008 columns: 58 tiles of 192 per block = 464 tiles = 2 rounds for 1.81;
+    //      64 tiles of 192 / 160 = 512 tiles, every workgroup one wide and one narrow tile).
+    //      Which of the two tile counts the host offers (the fewest, or its balanced alternative) is decided HERE, from
+    //      the row-block count the device-side expert counts actually give: rounds of the busiest workgroup x (average
+    //      fragments per tile + 1 for prologue / epilogue) -- the host's guess assumes even routing, and a count that evens
+    //      out 8 row blocks is a round too many for 13.
+    const int n_frag = (N + 31) >> 5;
+    auto pick_tiles = [&](int m_tiles) {
+        if (n_tiles_alt <= 0) return;
+        const int G = (int)gridDim.x;
+        const float ra = (float)((m_tiles * n_tiles_min + G - 1) / G), rb = (float)((m_tiles * n_tiles_alt + G - 1) / G);
+        const float ca = ra * (float)(n_frag + n_tiles_min) * (float)n_tiles_alt;      // r (F / t + 1), cross-multiplied
+        const float cb = rb * (float)(n_frag + n_tiles_alt) * (float)n_tiles_min;
+        if (cb < ca) n_tiles = n_tiles_alt;
+    };
     if (tpe != nullptr) {
         // One vector load per 64 experts (every wave does it redundantly; nothing is shared).
         int cp = 0, ct = 0;
         for (int base = 0; base < E; base += 64) (void)expert_chunk(tpe, offs, E, T, C::BM, base, lane, cp, ct);
-        const int m_tiles = ct < m_slots ? ct : m_slots;     // overlapping ranges: stay inside the plan
+        const int m_tiles = __builtin_amdgcn_readfirstlane(ct < m_slots ? ct : m_slots);     // overlapping ranges: stay inside the plan
+        pick_tiles(m_tiles);
         n_real = m_tiles * n_tiles;
+    } else {
+        pick_tiles(m_slots);
+        n_real = m_slots * n_tiles;
     }
+    n_tiles = __builtin_amdgcn_readfirstlane(n_tiles);
     n_real = __builtin_amdgcn_readfirstlane(n_real);
+    const int f_base = n_frag / n_tiles, f_rem = n_frag - f_base * n_tiles;
 
     auto tile_params = [&](int vb) -> GemmTile {             // wave-uniform
         GemmTile tp = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -154,6 +183,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
         const int tile = xcd_remap(vb, n_real);
         const int ms = tile / n_tiles;
         tp.nt = tile - ms * n_tiles;
+        tp.nfr = f_base + (tp.nt < f_rem ? 1 : 0);
+        tp.n0 = (tp.nt * f_base + (tp.nt < f_rem ? tp.nt : f_rem)) * 32;
         if (tpe == nullptr) {                                // linear: one group covering all T rows
             tp.row0 = tp.prow0 = ms * C::BM;
             tp.rows_valid = T - tp.row0;
@@ -182,6 +213,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
         tp.prow0 = __builtin_amdgcn_readfirstlane(tp.prow0);
         tp.rows_valid = __builtin_amdgcn_readfirstlane(tp.rows_valid);
         tp.nt = __builtin_amdgcn_readfirstlane(tp.nt);
+        tp.n0 = __builtin_amdgcn_readfirstlane(tp.n0);
+        tp.nfr = __builtin_amdgcn_readfirstlane(tp.nfr);
         tp.ok = __builtin_amdgcn_readfirstlane(tp.ok);
         return tp;
     };
@@ -221,12 +254,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     // first loads of a tile.  Every load is UNCONDITIONAL (a missing tile, rows past N and columns past N read
     // zero through the descriptors): a load under an `if` makes hipcc's counted vmcnt collapse to "wait for
     // almost everything", which throws the prefetch lead away.
+    // scalar offset of weight piece i (rows 8 (i NW + wave) .. + 7 of the tile): past the tile's own fragments the rows
+    // belong to the next tile -- out of bounds, so they read zero and cost no traffic
+    auto piece_off = [&](int so, int i, int nfr) -> int { return (8 * (i * C::NW + wave) < nfr * 32) ? so + i * pieceB : OOB; };
     auto issue_prologue = [&](const GemmTile &tp) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(packed + (size_t)tp.e * wbytes), 0, (int)wbytes, 0x00020000);
-        const int sB = tp.ok ? tp.nt * C::BN * (K >> 1) : OOB;
+        const int sB = tp.ok ? tp.n0 * (K >> 1) : OOB;
 #pragma unroll
-        for (int i = 0; i < C::CPWB; ++i) bst[0][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voffB0, sB + i * pieceB, FQL_WIDE_W_AUX);
+        for (int i = 0; i < C::CPWB; ++i) bst[0][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voffB0, piece_off(sB, i, tp.nfr), FQL_WIDE_W_AUX);
         const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(scales + (size_t)tp.e * N), 0, N * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(
@@ -239,7 +275,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
             const int arr = idx < C::BN ? 0 : (idx < 2 * C::BN ? 1 : 2);
             const int col = idx - arr * C::BN;
             const int so = (tp.ok && idx < 3 * C::BN) ? 0 : OOB;
-            const int vo = (tp.nt * C::BN + col) * 4;
+            const int vo = (tp.n0 + col) * 4;
             const int vs = __builtin_amdgcn_raw_buffer_load_b32(rsS, arr == 0 ? vo : OOB, so, 0);
             const int vz = __builtin_amdgcn_raw_buffer_load_b32(rsZ, arr == 1 ? vo : OOB, so, 0);
             const int vb = __builtin_amdgcn_raw_buffer_load_b32(rsBi, arr == 2 ? vo : OOB, so, 0);
@@ -261,7 +297,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     FQL_WSTAMP(ev++, 1);                                     // tile start, constant 100 MHz clock
     FQL_WSTAMP(ev++, 0);                                     // tile start, shader clock
     const int e = cur.e, row0 = cur.row0, rows_valid = cur.rows_valid;
-    const int n0 = cur.nt * C::BN;
+    const int n0 = cur.n0, nfr = cur.nfr;
+    const int nfw = nfr - wn * NF < 0 ? 0 : (nfr - wn * NF > NF ? NF : nfr - wn * NF);   // this wave's fragments that exist
     const bool rpass = RES && cur.rp != 0;                   // residual pass: second limb set, partials to the scratch slot
     const bool active = cur.ok && wm * FQL_MB < rows_valid; // waves past the expert's last row only help stage weights
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
@@ -290,9 +327,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     for (int s = 1; s <= BD; ++s)
 #pragma unroll
         for (int i = 0; i < C::CPWB; ++i)
-            bst[s % BD][i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB0, (s < KT ? sB + s * (FQL_KB / 2) : OOB) + i * pieceB, FQL_WIDE_W_AUX);
+            bst[s % BD][i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB0, piece_off(s < KT ? sB + s * (FQL_KB / 2) : OOB, i, nfr), FQL_WIDE_W_AUX);
 
-    if (active) {
+    // The K loop exists in two forms: all NF fragments of this wave, or NF - 1 when the tile is one fragment narrower
+    // and the missing fragment is this wave's last (tile_params: tiles of a row block differ by at most one fragment).
+    // Fewer fragments still (the ragged last tile of N, shapes narrower than a tile) run the full form on zeros, as ever.
+    auto k_loop = [&](auto nfa_tag) {
+        constexpr int NFA = decltype(nfa_tag)::value;
         // ---- the weight fragments are software-pipelined one k-step ahead: the ds_reads of the next 64-k
         //      pair and the nibble unpack of the next step are issued under the current step's MFMAs.  One
         //      barrier per stage, placed at step 5: by then every wave has parked stage kt+1 (its step 0) and
@@ -309,7 +350,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
         // hand-over from "next" to "current" costs no register moves
         v4i bfr2[2][NF], braw2[2][NF];
 #pragma unroll
-        for (int j = 0; j < NF; ++j) {
+        for (int j = 0; j < NFA; ++j) {
             braw2[0][j] = *reinterpret_cast<const v4i *>(lds + rB0 + j * 4096 + 16 * ((0 + g) ^ swB0));
             uint32_t lo0, hi0, lo1, hi1;
             unpack8((uint32_t)braw2[0][j][0], lo0, hi0);
@@ -338,7 +379,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
 #pragma unroll
                     for (int i = 0; i < C::CPWB; ++i)
                         bst[(kk + 1) % BD][i] =
-                            __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB0, sNext + i * pieceB, FQL_WIDE_W_AUX);
+                            __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB0, piece_off(sNext, i, nfr), FQL_WIDE_W_AUX);
                 }
                 if (ks == 5) {
                     wait_lgkmcnt0();
@@ -348,21 +389,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
                     const char *src = (v < 3) ? sb : nb;
                     const int nv = (v + 1) & 3;
 #pragma unroll
-                    for (int j = 0; j < NF; ++j)
+                    for (int j = 0; j < NFA; ++j)
                         braw2[pn][j] = *reinterpret_cast<const v4i *>(src + rB0 + j * 4096 + 16 * ((2 * nv + g) ^ swB0));
                 }
 #if defined(FQL_ABLATE) && FQL_ABLATE == 1
 #pragma unroll
                 for (int l = 0; l < L; ++l) asm volatile("" ::"v"(afr[ks % D][l]));
 #pragma unroll
-                for (int j = 0; j < NF; ++j) asm volatile("" ::"v"(bfr2[b][j]));
+                for (int j = 0; j < NFA; ++j) asm volatile("" ::"v"(bfr2[b][j]));
 #else
                 if constexpr (F8) {
                     if (b == 1) {              // steps ks-1 and ks together: 64 k per instruction
                         const v8i a8 = {afr[(ks - 1) % D][0][0], afr[(ks - 1) % D][0][1], afr[(ks - 1) % D][0][2], afr[(ks - 1) % D][0][3],
                                         afr[ks % D][0][0], afr[ks % D][0][1], afr[ks % D][0][2], afr[ks % D][0][3]};
 #pragma unroll
-                        for (int j = 0; j < NF; ++j) {
+                        for (int j = 0; j < NFA; ++j) {
                             const v8i w8 = {bfr2[0][j][0], bfr2[0][j][1], bfr2[0][j][2], bfr2[0][j][3],
                                             bfr2[1][j][0], bfr2[1][j][1], bfr2[1][j][2], bfr2[1][j][3]};
                             acc[0][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8, a8, acc[0][j], 0, 0, 0, FQL_E8M0_2P9, 0, FQL_E8M0_ONE);
@@ -372,12 +413,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
 #pragma unroll
                     for (int l = 0; l < L; ++l)
 #pragma unroll
-                        for (int j = 0; j < NF; ++j)
+                        for (int j = 0; j < NFA; ++j)
                             acc[l][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bfr2[b][j], afr[ks % D][l], acc[l][j], 0, 0, 0);
                 }
 #endif
 #pragma unroll
-                for (int j = 0; j < NF; ++j) {  // unpack for the next step under the MFMAs
+                for (int j = 0; j < NFA; ++j) {  // unpack for the next step under the MFMAs
                     uint32_t lo0, hi0, lo1, hi1;
                     if (b == 0) {
                         unpack8((uint32_t)braw2[pc][j][2], lo0, hi0);
@@ -415,6 +456,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
           }
         }
         wait_lgkmcnt0();
+    };
+    if (active) {
+        if constexpr (NF >= 2 && !F8) {
+            if (nfw == NF - 1) k_loop(std::integral_constant<int, NF - 1>{});
+            else k_loop(std::integral_constant<int, NF>{});
+        } else {
+            k_loop(std::integral_constant<int, NF>{});
+        }
     } else {
         // waves past the expert's last row: only help stage the weights and keep the barriers in step
         wait_lgkmcnt0();
@@ -431,7 +480,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
 #pragma unroll
             for (int i = 0; i < C::CPWB; ++i)
                 bst[(kk + 1) % BD][i] =
-                    __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB0, sNext + i * pieceB, FQL_WIDE_W_AUX);
+                    __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB0, piece_off(sNext, i, nfr), FQL_WIDE_W_AUX);
             wait_lgkmcnt0();
             __builtin_amdgcn_s_barrier();
           }
@@ -481,15 +530,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
         const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & (out_kind == 0 ? 15 : 7)) == 0);
         // (the lane part goes through an opaque register: otherwise the compiler hoists all NF * 4 slot pointers out of
         //  the persistent tile loop, keeps them live across the K loop and spills them -- 72 bytes of scratch per lane)
-        int lane4 = lane * 4;
+        int lane4 = lane * 4, g4 = 4 * g;
         asm volatile("" : "+v"(lane4));
+        asm volatile("" : "+v"(g4));                          // same for the column offsets of the scale / zero-point reads
         float *slot0 = (MODE == 0) ? nullptr
                                    : res_scratch + ((size_t)blockIdx.x * C::NW + wave) * (NF * 1024) + lane4;
 #pragma unroll
         for (int j = 0; j < NF; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int c0 = (wn * NF + j) * 32 + 8 * q + 4 * g;          // column inside the tile
+                if (j >= nfw) continue;                                      // columns of the next tile
+                const int c0 = (wn * NF + j) * 32 + 8 * q + g4;             // column inside the tile
                 const v4f s4 = *reinterpret_cast<const v4f *>(sz + c0);
                 const v4f z4 = *reinterpret_cast<const v4f *>(sz + C::BN + c0);
                 float o[4];

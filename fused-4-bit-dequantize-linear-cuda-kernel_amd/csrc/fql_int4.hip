@@ -20,6 +20,7 @@ namespace {
 // product call in a hipGraph: GEMV 9.3 / 12.1 / 19.7 us at B = 1 / 2 / 3, MFMA path 16.4 / 16.5 / 16.1 us at
 // B = 2 / 3 / 4 and 16.2-16.5 us at B = 5..16: profiles/r02_linear_batch_sweep.txt).  Tuning hook below.
 int g_gemv_max_rows = 2;
+int g_act_single_rows = 512;          // pre-pass: one row per workgroup up to this many padded rows (tuning hook below)
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline size_t round16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -186,9 +187,9 @@ int launch_act_quant(const void *x, int in_dtype, const int32_t *gather, int n_s
     // (MoE entry point) the workgroups that zero the rows of `out` no expert covers
     const int mblocks = (tpe == nullptr) ? (T + FQL_MB - 1) / FQL_MB : (T + FQL_MB * E) / FQL_MB;
     const bool vec = (K % 16 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
-    // few rows in all (at most four single-row workgroups per CU): one row per workgroup -- the pre-pass is a latency
+    // few rows in all (at most two single-row workgroups per CU; measured: 16 rows 6.3 -> 4.6 us, 1280 padded rows 12.5 -> 16.5 us): one row per workgroup -- the pre-pass is a latency
     // chain there and a row spread over 256 threads shortens every link of it (fql_act_quant.h)
-    const bool single = vec && mblocks * FQL_MB <= 1024;
+    const bool single = vec && mblocks * FQL_MB <= g_act_single_rows;
     const int rblocks = mblocks * (single ? FQL_MB : FQL_MB / ACT_ROWS);
     const int zblocks = (tpe != nullptr && out != nullptr) ? (T + 255) / 256 : 0;
     void (*kern)(const void *, const int32_t *, int, float *, int32_t *, int8_t *, int, int, int, int, int, void *, int,
@@ -216,6 +217,57 @@ int launch_act_quant(const void *x, int in_dtype, const int32_t *gather, int n_s
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
+// Column tiles per row block of the wide kernel.  The fewest that cover N (every tile at most `fpt` fragments of 32
+// columns) is the plain tiling; a few more, narrower tiles are chosen when that evens out what each persistent
+// workgroup walks (fql_gemm_i8.h, tile_params).  Cost model: a tile costs its fragments + 1 (prologue / epilogue),
+// the launch costs what its busiest workgroup walks; `m_tiles` is the row-block count under even routing (the real
+// count lives on the device).  Exact replay of the kernel's tile order, cached per shape.
+int g_balance_tiles = 1;
+inline int host_xcd_remap(int bid, int nblk)
+{
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (bid >> 3);
+}
+inline int balanced_n_tiles(int N, int fpt, long long m_tiles, int wgs)
+{
+    const int F = (N + 31) / 32;
+    const int tmin = (F + fpt - 1) / fpt;
+    if (!g_balance_tiles || m_tiles <= 0 || wgs <= 0 || wgs > 4096 || m_tiles * tmin > 8192) return tmin;
+    struct Key { int N, fpt, wgs; long long m_tiles; int result; };
+    static thread_local Key cache[8] = {};
+    static thread_local int next_slot = 0;
+    for (const Key &k : cache)
+        if (k.result > 0 && k.N == N && k.fpt == fpt && k.wgs == wgs && k.m_tiles == m_tiles) return k.result;
+    auto busiest = [&](int t) -> long long {
+        const long long n_real = m_tiles * t;
+        const int base = F / t, rem = F - base * t;
+        const int G = n_real < wgs ? (int)n_real : wgs;
+        static thread_local int cost[4096];
+        for (int i = 0; i < G; ++i) cost[i] = 0;
+        for (int vb = 0; vb < (int)n_real; ++vb) {
+            const int i = host_xcd_remap(vb, (int)n_real) % t;
+            cost[vb % G] += base + (i < rem ? 1 : 0) + 1;
+        }
+        int mx = 0;
+        for (int i = 0; i < G; ++i) mx = cost[i] > mx ? cost[i] : mx;
+        return mx;
+    };
+    int best = tmin;
+    long long best_cost = busiest(tmin);
+    // candidates: tile counts that make the launch a whole number of rounds
+    for (long long rounds = (m_tiles * tmin + wgs - 1) / wgs; rounds <= (m_tiles * tmin + wgs - 1) / wgs + 1; ++rounds) {
+        if ((rounds * wgs) % m_tiles != 0) continue;
+        const long long t = rounds * wgs / m_tiles;
+        if (t <= tmin || t > F || t > 2 * tmin) continue;
+        const long long c = busiest((int)t);
+        if (c < best_cost) { best_cost = c; best = (int)t; }
+    }
+    cache[next_slot] = Key{N, fpt, wgs, m_tiles, best};
+    next_slot = (next_slot + 1) & 7;
+    return best;
+}
+
 template <int L, int WM, int WN, int NF, int DEPTH, int BDEPTH, bool F8 = false>
 int launch_gemm_cfg(const Workspace &w, const uint8_t *packed, const float *scales, const float *zps,
                     void *out, int out_dtype, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp,
@@ -226,15 +278,19 @@ int launch_gemm_cfg(const Workspace &w, const uint8_t *packed, const float *scal
     static PerDeviceFlag attr;
     if (!ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), C::LDS_BYTES)) return FQL_ERR_LAUNCH;
     (void)hipGetLastError();                                 // a stale error of another library must not read as ours
-    const int n_tiles = (N + C::BN - 1) / C::BN;
-    const int m_slots = (tpe == nullptr) ? (T + C::BM - 1) / C::BM : T / C::BM + E;
-    long long blocks = (long long)n_tiles * m_slots;        // worst-case tile count (real count is on the device)
-    if (blocks <= 0 || blocks > 0x7fffffffLL) return FQL_ERR_BAD_SHAPE;
     // persistent: the 8-wave workgroups fill a CU alone; the small skinny-tile workgroups share it 4 / 8 ways
     const int cus = compute_units() * (C::NW >= 8 ? 1 : (C::NW == 4 ? 2 : 4));      // 2 waves per SIMD either way
+    const int m_slots = (tpe == nullptr) ? (T + C::BM - 1) / C::BM : T / C::BM + E;
+    const int groups = (tpe == nullptr) ? 1 : E;
+    const long long m_even = (long long)groups * (((T + groups - 1) / groups + C::BM - 1) / C::BM);   // row blocks if evenly routed
+    const int n_tiles = (N + C::BN - 1) / C::BN;            // the fewest column tiles that cover N ...
+    int n_alt = (NF >= 2 && !F8) ? balanced_n_tiles(N, C::BN / 32, m_even, cus) : n_tiles;   // ... and the balanced alternative;
+    if (n_alt == n_tiles) n_alt = 0;                         // the kernel picks between them from the real row-block count
+    long long blocks = (long long)(n_alt > n_tiles ? n_alt : n_tiles) * m_slots;   // worst-case tile count (real count is on the device)
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return FQL_ERR_BAD_SHAPE;
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, w.limbs, w.delta, w.rowsum,
-                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch, w.bias);
+                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch, w.bias, n_alt);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
@@ -939,6 +995,8 @@ FQL_API int fql_debug_trace(unsigned long long *dst)
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(fql_trace_buf), sizeof(unsigned long long) * 8 * 64) == hipSuccess ? 0 : -1;
 }
 #endif
+FQL_API int fql_tune_set_act_single_rows(int rows) { const int old = g_act_single_rows; if (rows >= 0) g_act_single_rows = rows; return old; }
+FQL_API int fql_tune_set_balance_tiles(int on) { const int old = g_balance_tiles; g_balance_tiles = on ? 1 : 0; return old; }
 FQL_API int fql_tune_set_gemv_max_rows(int rows) { const int old = g_gemv_max_rows; if (rows >= 0 && rows <= 4) g_gemv_max_rows = rows; return old; }
 FQL_API int fql_tune_num_configs(void) { return FQL_NUM_CFG; }
 FQL_API int fql_tune_num_rows32_configs(void) { return FQL_NUM_ROWS32; }

@@ -664,6 +664,24 @@ def test_full_size_moe_properties(fq):
     # (c) grouped launch == single-expert launch on the same rows, bit for bit
     single = ops.linear_forward(x[256:384].contiguous(), P[2], S[2], Z[2])
     assert torch.equal(single, out[256:384])
+    # (c') the balanced column tiling (64 tiles of 192 / 160 columns per row block at this shape) returns the bits of
+    #      the plain one (58 tiles of 192), for even routing and for a ragged one where the kernel itself falls back
+    #      to the plain tiling
+    from fused_int4_amd import _native
+    lib = _native.lib()
+    cnt2 = torch.tensor([485, 312, 126, 48, 30, 13, 6, 4], dtype=torch.int32, device="cuda")
+    offs2 = torch.cumsum(cnt2, 0).to(torch.int32) - cnt2
+    out_r = ops.moe_forward(P, S, Z, x, None, cnt2, offs2)
+    try:
+        assert lib.fql_tune_set_balance_tiles(0) == 1
+        assert torch.equal(ops.moe_forward(P, S, Z, x, None, cnt, offs), out)
+        assert torch.equal(ops.moe_forward(P, S, Z, x, None, cnt2, offs2), out_r)
+    finally:
+        lib.fql_tune_set_balance_tiles(1)
+    r0 = 485 + 312 + 126 + 48 + 30 + 13                       # the two rows of the 6-row expert and the 4-row expert's first
+    for r, e in ((r0, 6), (r0 + 5, 6), (r0 + 6, 7)):
+        ref = C.linear_f64acc(x[r].cpu().numpy(), Pn[e], Sn[e], Zn[e])
+        assert rel_fro(out_r[r].cpu().numpy(), ref) < EXACT_REL_FRO, r
     # (d) checksum of checksums: sum_n out[t,n] == x[t] . (sum_n W[n,:])
     wsum = fq.dequantize_weights(P[5], S[5], Z[5]).double().sum(0)
     lhs = out[640:768].double().sum(1)

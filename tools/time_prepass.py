@@ -3,6 +3,9 @@ sys.path.insert(0, "/root/repo")
 import fused_int4_amd as fq
 from fused_int4_amd import ops
 dev = torch.device("cuda:0")
+if len(sys.argv) > 1:
+    from fused_int4_amd import _native
+    print("act single rows", _native.lib().fql_tune_set_act_single_rows(int(sys.argv[1])), "->", sys.argv[1])
 E, T, K = 8, 1024, 4096
 x = torch.randn(T, K, device=dev)
 xs = [torch.randn(T, K, device=dev) for _ in range(24)]   # rotate: 400 MB > infinity cache

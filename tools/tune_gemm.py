@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--top-k", type=int, default=2)
     ap.add_argument("--static-too", action="store_true", help="also time every configuration without scratch: static tile order, no residual pass (ids 2000 + cfg)")
     ap.add_argument("--alt-lib", default="", help="a second build of libfql_int4.so: every configuration is also timed through it (ids 1000 + cfg)")
+    ap.add_argument("--plain-too", action="store_true", help="also time every configuration with the plain BN-wide column tiling instead of the balanced tile widths (ids 3000 + cfg)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _native.lib()
@@ -50,6 +51,8 @@ def main():
         cfgs = cfgs + [1000 + c for c in base_cfgs]
     if a.static_too:
         cfgs = cfgs + [2000 + c for c in base_cfgs]
+    if a.plain_too:
+        cfgs = cfgs + [3000 + c for c in base_cfgs]
     prec = {"exact": 3, "fast": 2, "int8": 1, "fp8": 8}[a.precision]
     E, K, N = a.experts, a.hidden, a.ffn
 
@@ -92,7 +95,8 @@ def main():
     def run(cfg, si, out):
         P, S, Z = sets[si % len(sets)]
         fn = alt if 1000 <= cfg < 2000 else tune
-        sc = None if cfg >= 2000 else scratch
+        sc = None if 2000 <= cfg < 3000 else scratch
+        lib.fql_tune_set_balance_tiles(0 if cfg >= 3000 else 1)
         cfg = cfg % 1000
         rc = fn(cfg, limbs.data_ptr(), delta.data_ptr(), rowsum.data_ptr(), P.data_ptr(), S.data_ptr(), Z.data_ptr(),
                   tp, of, out.data_ptr(), En, T, K, N, prec, stream,
