@@ -259,7 +259,7 @@ inline int balanced_n_tiles(int N, int fpt, long long m_tiles, int wgs)
     for (long long rounds = (m_tiles * tmin + wgs - 1) / wgs; rounds <= (m_tiles * tmin + wgs - 1) / wgs + 1; ++rounds) {
         if ((rounds * wgs) % m_tiles != 0) continue;
         const long long t = rounds * wgs / m_tiles;
-        if (t <= tmin || t > F || t > 2 * tmin) continue;
+        if (t <= tmin || t > F || F / t < fpt - 1) continue;   // the K loop has a form for one fragment less than a full tile, not fewer
         const long long c = busiest((int)t);
         if (c < best_cost) { best_cost = c; best = (int)t; }
     }

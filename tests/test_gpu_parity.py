@@ -709,6 +709,34 @@ def test_full_size_linear_b512(fq):
     assert rel_fro(of[:16].cpu().numpy(), out[:16].cpu().numpy()) < FAST_REL_FRO
 
 
+def test_balanced_column_tiles_ragged_n(fq):
+    """Uneven column tiles (fql_gemm_i8.h, tile_params) on a shape where the balanced tile count differs from the plain
+    one AND N is not a multiple of the fragment width: 16 row blocks x 170 fragments (the last one 29 columns wide) =
+    464 plain tiles on 256 CUs -> 32 tiles of 6 / 5 fragments per block.  Against the float64 oracle, and bit for bit
+    against the plain tiling."""
+    from fused_int4_amd import ops, _native
+    lib = _native.lib()
+    B, N, K = 2048, 5437, 256
+    x, p, s, z = make_problem(N, K, B, 5437)
+    dx, dp, ds, dz = dev(x), dev(p), dev(s), dev(z)
+    out = ops.linear_forward(dx, dp, ds, dz)
+    ref = C.linear_f64acc(x, p, s, z)
+    assert rel_fro(out.cpu().numpy(), ref) < EXACT_REL_FRO
+    try:
+        assert lib.fql_tune_set_balance_tiles(0) == 1
+        plain = ops.linear_forward(dx, dp, ds, dz)
+    finally:
+        lib.fql_tune_set_balance_tiles(1)
+    assert torch.equal(out, plain)
+    for prec in ("fast", "int8"):
+        o = ops.linear_forward(dx, dp, ds, dz, precision=prec)
+        try:
+            lib.fql_tune_set_balance_tiles(0)
+            assert torch.equal(o, ops.linear_forward(dx, dp, ds, dz, precision=prec)), prec
+        finally:
+            lib.fql_tune_set_balance_tiles(1)
+
+
 # ------------------------------------------------------------------------------ per-group scales along K (SURVEY 8f N3)
 @pytest.mark.parametrize("B,N,K,group", [(1, 64, 256, 64), (7, 200, 512, 128), (40, 96, 1024, 32), (3, 33, 96, 2)])
 def test_per_group_scales_linear(fq, B, N, K, group):
