@@ -57,8 +57,8 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_rows16_kernel(
     const int32_t *__restrict__ rowsum, const uint8_t *__restrict__ packed,
     const float *__restrict__ scales, const float *__restrict__ zps, void *__restrict__ out, int out_kind,
     const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
-    int E, int T, int K, int Kp, int MBT, int N, int n_tiles, int m_slots, float *__restrict__ res_scratch,
-    const float *__restrict__ bias)
+    int E, int T, int K, int Kp, int MBT, int N, int n_tiles_min, int m_slots, float *__restrict__ res_scratch,
+    const float *__restrict__ bias, int n_tiles_alt)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = Rows16Cfg<L, NF, KG, BDEPTH>;
@@ -77,17 +77,39 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_rows16_kernel(
     //      experts fall back to re-reading per tile), so finding a tile's expert later costs no global load and no
     //      wait behind the weight stream
     __shared__ int s_lo[64], s_cnt[64], s_tex[64], s_pex[64];
-    int n_real = m_slots * n_tiles;
+    // ---- columns: the N / 16 fragments of a row block are dealt evenly to its tiles, the wider tiles first, and a
+    //      tile's fragments evenly to its NG column groups (this is a weight stream: what a workgroup walks is the bytes
+    //      it reads).  Of the two tile counts the host offers -- the fewest that cover N and a balanced alternative --
+    //      the one whose busiest workgroup walks less is picked here, from the row-block count the device-side expert
+    //      counts give (8 experts x <= 16 rows x 11008 columns: 86 tiles of 128 per block = 688 tiles = 3 rounds for
+    //      2.69; 96 tiles of 8 / 7 fragments = 768 tiles, three per workgroup).
+    const int n_frag = (N + 15) >> 4;
+    int n_tiles = n_tiles_min;
+    auto pick_tiles = [&](int m_tiles) {
+        if (n_tiles_alt <= 0) return;
+        const int G = (int)gridDim.x;
+        const float ra = (float)((m_tiles * n_tiles_min + G - 1) / G), rb = (float)((m_tiles * n_tiles_alt + G - 1) / G);
+        const float ca = ra * (float)(n_frag + 2 * n_tiles_min) * (float)n_tiles_alt;     // r (F / t + 2), cross-multiplied
+        const float cb = rb * (float)(n_frag + 2 * n_tiles_alt) * (float)n_tiles_min;
+        if (cb < ca) n_tiles = n_tiles_alt;
+    };
+    int n_real;
     if (tpe != nullptr) {
         int cp = 0, ct = 0;
         for (int base = 0; base < E; base += 64) {
             const ExpertLane x = expert_chunk(tpe, offs, E, T, C::BM, base, lane, cp, ct);
             if (base == 0 && wave == 0) { s_lo[lane] = x.lo; s_cnt[lane] = x.cnt; s_tex[lane] = x.tile_excl; s_pex[lane] = x.pad_excl; }
         }
-        const int m_tiles = ct < m_slots ? ct : m_slots;
+        const int m_tiles = __builtin_amdgcn_readfirstlane(ct < m_slots ? ct : m_slots);
+        pick_tiles(m_tiles);
         n_real = m_tiles * n_tiles;
+    } else {
+        pick_tiles(m_slots);
+        n_real = m_slots * n_tiles;
     }
+    n_tiles = __builtin_amdgcn_readfirstlane(n_tiles);
     n_real = __builtin_amdgcn_readfirstlane(n_real);
+    const int f_base = n_frag / n_tiles, f_rem = n_frag - f_base * n_tiles;
     __syncthreads();
 
     auto tile_params = [&](int vb) -> GemmTile {
@@ -96,6 +118,8 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_rows16_kernel(
         const int tile = xcd_remap(vb, n_real);
         const int ms = tile / n_tiles;
         tp.nt = tile - ms * n_tiles;
+        tp.nfr = f_base + (tp.nt < f_rem ? 1 : 0);
+        tp.n0 = (tp.nt * f_base + (tp.nt < f_rem ? tp.nt : f_rem)) * 16;
         if (tpe == nullptr) {
             tp.row0 = tp.prow0 = ms * C::BM;
             tp.rows_valid = T - tp.row0;
@@ -142,8 +166,16 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_rows16_kernel(
         tp.prow0 = __builtin_amdgcn_readfirstlane(tp.prow0);
         tp.rows_valid = __builtin_amdgcn_readfirstlane(tp.rows_valid);
         tp.nt = __builtin_amdgcn_readfirstlane(tp.nt);
+        tp.n0 = __builtin_amdgcn_readfirstlane(tp.n0);
+        tp.nfr = __builtin_amdgcn_readfirstlane(tp.nfr);
         tp.ok = __builtin_amdgcn_readfirstlane(tp.ok);
         return tp;
+    };
+    // this wave's share of a tile's fragments: column group ng takes fragments [ng * nf0, ng * nf0 + nfw) of the tile
+    auto frag0 = [&](const GemmTile &tp) -> int { return ng * ((tp.nfr + NG - 1) / NG); };
+    auto frags = [&](const GemmTile &tp) -> int {
+        const int nf0 = (tp.nfr + NG - 1) / NG, left = tp.nfr - ng * nf0;
+        return left < 0 ? 0 : (left > nf0 ? nf0 : left);
     };
 
     const int KB = Kp / FQL_KB, KT = KB;
@@ -174,7 +206,7 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_rows16_kernel(
     };
     auto w_soff = [&](const GemmTile &tp, int s) -> int {      // stage s of this K group in tile tp, or out of bounds
         const int kt = kg + s * KG;
-        return (tp.ok && kt < KT) ? (tp.nt * C::BN + ng * NF * 16) * (K >> 1) + kt * (FQL_KB / 2) : OOB;
+        return (tp.ok && kt < KT) ? (tp.n0 + frag0(tp) * 16) * (K >> 1) + kt * (FQL_KB / 2) : OOB;
     };
     auto a_soff = [&](const GemmTile &tp, int s) -> int {
         const int kt = kg + s * KG;
@@ -187,10 +219,10 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_rows16_kernel(
     float szr[C::SZN];
     int drow[1 + L];                                           // delta bits and limb row sums of this lane's row
     int d2bits = 0;                                            // delta2 bits of this lane's row (heavy-tailed rows: fql_gemm_i8.h)
-    auto issue_weights = [&](const __amdgpu_buffer_rsrc_t rs, int so, int slot) {
+    auto issue_weights = [&](const __amdgpu_buffer_rsrc_t rs, int so, int slot, int nfw) {   // pieces past this wave's fragments: no traffic
 #pragma unroll
         for (int i = 0; i < C::PIECES; ++i)
-            bst[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vrel0, so + i * 8 * (K >> 1), FQL_W_AUX);
+            bst[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(rs, vrel0, (8 * i < 16 * nfw) ? so + i * 8 * (K >> 1) : OOB, FQL_W_AUX);
     };
     auto issue_acts = [&](int so, int par) {
 #if defined(FQL_ABLATE) && FQL_ABLATE == 2          // timing experiment only (wrong results): no activation traffic
@@ -215,7 +247,7 @@ const __amdgpu_buffer_rsrc_t rsBi = __builtin_amdgcn_make_buffer_rsrc(
             const int arr = idx < C::BN ? 0 : (idx < 2 * C::BN ? 1 : 2);
             const int col = idx - arr * C::BN;
             const int so = (tp.ok && idx < 3 * C::BN) ? 0 : OOB;
-            const int vo = (tp.nt * C::BN + col) * 4;
+            const int vo = (tp.n0 + col) * 4;
             const int vs = __builtin_amdgcn_raw_buffer_load_b32(rsS, arr == 0 ? vo : OOB, so, 0);
             const int vz = __builtin_amdgcn_raw_buffer_load_b32(rsZ, arr == 1 ? vo : OOB, so, 0);
             const int vb = __builtin_amdgcn_raw_buffer_load_b32(rsBi, arr == 2 ? vo : OOB, so, 0);
@@ -239,7 +271,7 @@ const __amdgpu_buffer_rsrc_t rsBi = __builtin_amdgcn_make_buffer_rsrc(
         // does have such rows re-issues its activations and constants for the residual pass
         const __amdgpu_buffer_rsrc_t rs = w_rsrc(cur);
 #pragma unroll
-        for (int u = 0; u < BD; ++u) issue_weights(rs, w_soff(cur, u), u);
+        for (int u = 0; u < BD; ++u) issue_weights(rs, w_soff(cur, u), u, frags(cur));
         issue_acts(a_soff(cur, 0), 0);
         issue_tile_consts(cur);
         if constexpr (RES) {
@@ -273,6 +305,7 @@ const __amdgpu_buffer_rsrc_t rsBi = __builtin_amdgcn_make_buffer_rsrc(
     if constexpr (RES) pb = residual_probe_issue(delta, T, nxt, C::BM, lane, res_scratch != nullptr && !rpass);
     FQL_STAMP(ev++);                                           // next tile known
     const __amdgpu_buffer_rsrc_t rs_cur = w_rsrc(cur), rs_nxt = w_rsrc(nxt);
+    const int nfw_cur = frags(cur), nfw_nxt = frags(nxt), fr0_cur = frag0(cur);
     float *sz = szbuf + parity * 3 * C::BN;
     // this tile's constants arrived with its first stage: park the scale slice, keep the row values
 #pragma unroll
@@ -309,7 +342,7 @@ const __amdgpu_buffer_rsrc_t rsBi = __builtin_amdgcn_make_buffer_rsrc(
             issue_acts(ahere ? a_soff(cur, s + 1) : a_soff(nxt, 0), apar ^ 1);
             if (s + 1 == SP) issue_tile_consts(nxt);          // with the next tile's first activation stage
             const bool here = s + BD < SP;
-            issue_weights(here ? rs_cur : rs_nxt, here ? w_soff(cur, s + BD) : w_soff(nxt, s + BD - SP), u);
+            issue_weights(here ? rs_cur : rs_nxt, here ? w_soff(cur, s + BD) : w_soff(nxt, s + BD - SP), u, here ? nfw_cur : nfw_nxt);
         }
         // ---- 4 MFMA steps of 64 k: LDS reads, unpack, matrix cores; no memory instruction in here
 #pragma unroll
@@ -400,7 +433,8 @@ const __amdgpu_buffer_rsrc_t rsBi = __builtin_amdgcn_make_buffer_rsrc(
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
             if (C::FLAT && j % KG != kg) continue;              // finished by the wave that summed it
-            const int c0 = (ng * NF + j) * 16 + 4 * kq;           // column inside the tile
+            if (j >= nfw_cur) continue;                         // columns of the next tile
+            const int c0 = (fr0_cur + j) * 16 + 4 * kq;           // column inside the tile
             const v4f s4 = *reinterpret_cast<const v4f *>(sz + c0);
             const v4f z4 = *reinterpret_cast<const v4f *>(sz + C::BN + c0);
             float o[4];
@@ -427,7 +461,7 @@ const __amdgpu_buffer_rsrc_t rsBi = __builtin_amdgcn_make_buffer_rsrc(
 #pragma unroll
                     for (int c = 0; c < 4; ++c) o[c] += b4[c];
                 }
-                store_out4(out, out_kind, (size_t)t * N, done.nt * C::BN + c0, N, vec, o);
+                store_out4(out, out_kind, (size_t)t * N, done.n0 + c0, N, vec, o);
             }
         }
     };

@@ -229,16 +229,17 @@ inline int host_xcd_remap(int bid, int nblk)
     const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
     return base + (bid >> 3);
 }
-inline int balanced_n_tiles(int N, int fpt, long long m_tiles, int wgs)
+inline int balanced_n_tiles(int N, int fpt, long long m_tiles, int wgs, int frag = 32, int overhead = 1, int min_base = -1)
 {
-    const int F = (N + 31) / 32;
+    if (min_base < 0) min_base = fpt - 1;                    // wide kernel: its K loop has a form for one fragment less than a full tile, not fewer
+    const int F = (N + frag - 1) / frag;
     const int tmin = (F + fpt - 1) / fpt;
     if (!g_balance_tiles || m_tiles <= 0 || wgs <= 0 || wgs > 4096 || m_tiles * tmin > 8192) return tmin;
-    struct Key { int N, fpt, wgs; long long m_tiles; int result; };
+    struct Key { int N, fpt, wgs, frag; long long m_tiles; int result; };
     static thread_local Key cache[8] = {};
     static thread_local int next_slot = 0;
     for (const Key &k : cache)
-        if (k.result > 0 && k.N == N && k.fpt == fpt && k.wgs == wgs && k.m_tiles == m_tiles) return k.result;
+        if (k.result > 0 && k.N == N && k.fpt == fpt && k.wgs == wgs && k.frag == frag && k.m_tiles == m_tiles) return k.result;
     auto busiest = [&](int t) -> long long {
         const long long n_real = m_tiles * t;
         const int base = F / t, rem = F - base * t;
@@ -247,7 +248,7 @@ inline int balanced_n_tiles(int N, int fpt, long long m_tiles, int wgs)
         for (int i = 0; i < G; ++i) cost[i] = 0;
         for (int vb = 0; vb < (int)n_real; ++vb) {
             const int i = host_xcd_remap(vb, (int)n_real) % t;
-            cost[vb % G] += base + (i < rem ? 1 : 0) + 1;
+            cost[vb % G] += base + (i < rem ? 1 : 0) + overhead;
         }
         int mx = 0;
         for (int i = 0; i < G; ++i) mx = cost[i] > mx ? cost[i] : mx;
@@ -259,11 +260,11 @@ inline int balanced_n_tiles(int N, int fpt, long long m_tiles, int wgs)
     for (long long rounds = (m_tiles * tmin + wgs - 1) / wgs; rounds <= (m_tiles * tmin + wgs - 1) / wgs + 1; ++rounds) {
         if ((rounds * wgs) % m_tiles != 0) continue;
         const long long t = rounds * wgs / m_tiles;
-        if (t <= tmin || t > F || F / t < fpt - 1) continue;   // the K loop has a form for one fragment less than a full tile, not fewer
+        if (t <= tmin || t > F || F / t < min_base) continue;
         const long long c = busiest((int)t);
         if (c < best_cost) { best_cost = c; best = (int)t; }
     }
-    cache[next_slot] = Key{N, fpt, wgs, m_tiles, best};
+    cache[next_slot] = Key{N, fpt, wgs, frag, m_tiles, best};
     next_slot = (next_slot + 1) & 7;
     return best;
 }
@@ -327,12 +328,16 @@ int launch_rows16_cfg(const Workspace &w, const uint8_t *packed, const float *sc
     (void)hipGetLastError();                                 // a stale error of another library must not read as ours
     const int n_tiles = (N + C::BN - 1) / C::BN;
     const int m_slots = (tpe == nullptr) ? (T + C::BM - 1) / C::BM : T / C::BM + E;
-    long long blocks = (long long)n_tiles * m_slots;
-    if (blocks <= 0 || blocks > 0x7fffffffLL) return FQL_ERR_BAD_SHAPE;
     const int cus = compute_units();
+    const int groups = (tpe == nullptr) ? 1 : E;
+    const long long m_even = (long long)groups * (((T + groups - 1) / groups + C::BM - 1) / C::BM);   // row blocks if evenly routed
+    int n_alt = balanced_n_tiles(N, C::BN / 16, m_even, cus, 16, 2, 1);     // uneven column tiles (fql_gemm_rows16.h)
+    if (n_alt == n_tiles) n_alt = 0;
+    long long blocks = (long long)(n_alt > n_tiles ? n_alt : n_tiles) * m_slots;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return FQL_ERR_BAD_SHAPE;
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, w.limbs, w.delta, w.rowsum,
-                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch, w.bias);
+                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch, w.bias, n_alt);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
