@@ -138,9 +138,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // wave w runs on SIMD w % 4: the two waves of a SIMD are the two COLUMN halves of one 32-row block (same wm, wn = 0 / 1),
-    // so a tile that is one fragment narrower (below) takes that fragment's MFMAs off every SIMD alike
-    const int wm = wave % WM, wn = wave / WM;
     const int l31 = lane & 31, g = lane >> 5;
     int n_tiles = n_tiles_min;
     int n_real = m_slots * n_tiles;
@@ -240,9 +237,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     const int voffB0 = row0B * (K >> 1) + chB * 16;
     const int pieceB = 8 * C::NW * (K >> 1);
     const int wB0 = row0B * 128 + 16 * (chB ^ ((row0B >> 1) & 7));      // swizzled LDS image
-    const int nB0 = wn * NF * 32 + l31;
-    const int rB0 = nB0 * 128;
-    const int swB0 = (nB0 >> 1) & 7;
+    const int swB0 = (l31 >> 1) & 7;                                     // (32-row steps do not move the swizzle)
     // scale / zero-point slice of a tile: 2 * BN floats through LDS (thread i < BN: scale of column i, thread
     // BN + i: zero point), double buffered by tile parity so the epilogue needs no global loads for them
     float *szbuf = reinterpret_cast<float *>(lds + 2 * C::B_STAGE);
@@ -298,6 +293,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     FQL_WSTAMP(ev++, 0);                                     // tile start, shader clock
     const int e = cur.e, row0 = cur.row0, rows_valid = cur.rows_valid;
     const int n0 = cur.n0, nfr = cur.nfr;
+    // Which wave takes which 32-row block (wm) and column half (wn) is decided per tile.  Wave w runs on SIMD w % 4, so
+    //   wm = w % WM, wn = w / WM puts the column halves of one row block on one SIMD: a tile that is one fragment
+    //     narrower (tile_params) takes that fragment's MFMAs off every SIMD alike (a full tile: -3 %);
+    //   wm = w / WN, wn = w % WN puts two different row blocks on a SIMD: when at most half of the row blocks hold rows
+    //     (a short group inside a 128-row tile) every SIMD keeps one working wave instead of half the SIMDs two (-14 %).
+    const bool spread_rows = rows_valid <= (WM / 2) * FQL_MB;
+    const int wm = spread_rows ? wave / WN : wave % WM, wn = spread_rows ? wave % WN : wave / WM;
+    const int rB0 = (wn * NF * 32 + l31) * 128;
     const int nfw = nfr - wn * NF < 0 ? 0 : (nfr - wn * NF > NF ? NF : nfr - wn * NF);   // this wave's fragments that exist
     const bool rpass = RES && cur.rp != 0;                   // residual pass: second limb set, partials to the scratch slot
     const bool active = cur.ok && wm * FQL_MB < rows_valid; // waves past the expert's last row only help stage weights
