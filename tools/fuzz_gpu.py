@@ -11,7 +11,7 @@ from fused_int4_amd import ops
 from oracle import oracle as O, c_oracle as C
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rng = np.random.default_rng(2024)
-TOL = {"exact": 2e-6, "fast": 2e-4, "int8": 1.5e-2}
+TOL = {"exact": 2e-6, "fast": 3e-4, "int8": 2.5e-2}
 worst = {}
 def rel(a, b):
     d = np.linalg.norm(b.astype(np.float64)); return np.linalg.norm(a.astype(np.float64) - b) / (d if d else 1.0)
@@ -35,6 +35,8 @@ for case in range(n_cases):
             P.append(p); S.append(s); Z.append(z)
         P, S, Z = np.stack(P), np.stack(S), np.stack(Z)
         x = rng.standard_normal((T, K)).astype(np.float32)
+        if case % 6 == 4 and prec != "int8":
+            x[::3, rng.integers(0, K, size=1)] *= 600.0
         ref = C.moe_grouped(P, S, Z, x, counts, offs)
         d = lambda a: torch.from_numpy(a).cuda()
         out = ops.moe_forward(d(P), d(S), d(Z), d(x), None, d(counts), d(offs), precision=prec).cpu().numpy()
@@ -45,13 +47,17 @@ for case in range(n_cases):
             assert torch.equal(h, w), ("f16 io", case, E, N, K, counts)
     else:
         B = int(rng.choice([1, 2, 3, 4, 5, 9, 16, 17, 33, 64, 130]))
+        if case % 10 == 9:              # many tiles: more than one round of the persistent launch, uneven column tiles
+            B, N, K = int(rng.choice([600, 1500, 2300])), int(rng.choice([3000, 5437, 6200])), int(rng.choice([64, 256]))
         p, s, z = O.quantize_weights((rng.standard_normal((N, K)) * 0.05).astype(np.float32))
         x = rng.standard_normal((B, K)).astype(np.float32)
+        if case % 5 == 3 and prec != "int8":   # heavy-tailed rows: outlier channels (residual limb set)
+            x[:, rng.integers(0, K, size=2)] *= float(rng.choice([50.0, 800.0]))
         ref = C.linear_f64acc(x, p, s, z)
         d = lambda a: torch.from_numpy(a).cuda()
         out = ops.linear_forward(d(x), d(p), d(s), d(z), precision=prec).cpu().numpy()
         key = f"linear/{prec}"
-    mfma = (K % 32 == 0) and (grouped or x.shape[0] > 4)
+    mfma = (K % 32 == 0) and (grouped or x.shape[0] > 2)
     tol = TOL[prec] if mfma else 2e-6
     if mfma and prec == "int8" and out.size < 2000:
         tol = 6e-2                      # 8-bit activations: few outputs -> the relative Frobenius error is noisy
