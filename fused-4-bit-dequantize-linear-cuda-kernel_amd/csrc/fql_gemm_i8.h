@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     n_real = __builtin_amdgcn_readfirstlane(n_real);
     const int f_base = n_frag / n_tiles, f_rem = n_frag - f_base * n_tiles;
 
-    auto tile_params = [&](int vb) -> GemmTile {             // wave-uniform
+    auto tile_params = [&](int vb, int lane) -> GemmTile {   // wave-uniform (lane passed in: see the note at the epilogue)
         GemmTile tp = {0, 0, 0, 0, 0, 0, 0, 0};
         if (vb >= n_real) return tp;
         const int tile = xcd_remap(vb, n_real);
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     // scalar offset of weight piece i (rows 8 (i NW + wave) .. + 7 of the tile): past the tile's own fragments the rows
     // belong to the next tile -- out of bounds, so they read zero and cost no traffic
     auto piece_off = [&](int so, int i, int nfr) -> int { return (8 * (i * C::NW + wave) < nfr * 32) ? so + i * pieceB : OOB; };
-    auto issue_prologue = [&](const GemmTile &tp) {
+    auto issue_prologue = [&](const GemmTile &tp, int tid) {   // (tid passed in: see the note at the epilogue)
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(packed + (size_t)tp.e * wbytes), 0, (int)wbytes, 0x00020000);
         const int sB = tp.ok ? tp.n0 * (K >> 1) : OOB;
@@ -279,13 +279,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     };
 
   int ev = 0;
-  GemmTile cur = tile_params(blockIdx.x);
+  GemmTile cur = tile_params(blockIdx.x, lane);
   if constexpr (RES) {
       const ResidualProbe pb = residual_probe_issue(delta, T, cur, C::BM, lane, res_scratch != nullptr);
-      issue_prologue(cur);
+      issue_prologue(cur, tid);
       cur.rp = residual_probe_eval(pb);
   } else {
-      issue_prologue(cur);
+      issue_prologue(cur, tid);
   }
   int parity = 0;
   for (int vb = blockIdx.x; vb < n_real; parity ^= 1) {      // one iteration per VISIT (tile, pass); vb advances below
@@ -496,9 +496,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     // loads are short and nothing slow is ahead of them in the load queue)
     GemmTile nxt;
     ResidualProbe pb = {0, 0};
+    // (per-lane values from here to the end of the visit are derived from an opaque copy of the thread id: derived from
+    //  the kernel-entry copies they are invariants of the persistent tile loop, live across the K loop, and spilled around it)
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, l31_e = lane_e & 31, g_e = lane_e >> 5;
     if (rpass) { nxt = cur; nxt.rp = 0; nxt.ad = 1; }
-    else { vb += (int)gridDim.x; nxt = tile_params(vb); }
-    if constexpr (RES) pb = residual_probe_issue(delta, T, nxt, C::BM, lane, res_scratch != nullptr && !rpass);   // evaluated after the epilogue
+    else { vb += (int)gridDim.x; nxt = tile_params(vb, lane_e); }
+    if constexpr (RES) pb = residual_probe_issue(delta, T, nxt, C::BM, lane_e, res_scratch != nullptr && !rpass);   // evaluated after the epilogue
     // ---- epilogue: fold zero-point, combine limbs, scale.  The weights are the MFMA's A operand (rows = n)
     //      and the activations its B operand (cols = t), so in the 32x32 C/D layout
     //      (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) every lane owns ONE output
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     //      scale / zero-point vectors from LDS, 16-byte stores.
     //      Order of issue matters (vector-memory loads complete in order): the four short per-row loads first,
     //      then the next tile's long HBM loads, then the arithmetic and the stores.
-    const int rl = wm * FQL_MB + l31;
+    const int rl = wm * FQL_MB + l31_e;
     const bool row_ok = active && rl < rows_valid;
     const int t = row_ok ? row0 + rl : 0;
     const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)delta, 0, (RES ? 2 : 1) * T * 4, 0x00020000);
@@ -520,7 +525,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     const int d2bits = RES ? __builtin_amdgcn_raw_buffer_load_b32(rsD, (T + t) * 4, 0, 0) : 0;   // unconditional load
     const bool addp = RES && (d2bits & 0x7fffffff) != 0;
     __builtin_amdgcn_sched_barrier(0);
-    issue_prologue(nxt);
+    issue_prologue(nxt, tid_e);
     __builtin_amdgcn_sched_barrier(0);
     // MODE 0: plain tile (the hot path: straight-line code, nothing of the residual machinery in it);
     // MODE 1: residual pass -- park the float32 results in this lane's scratch slot (workgroup-private; read back by
@@ -533,9 +538,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
         const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & (out_kind == 0 ? 15 : 7)) == 0);
         // (the lane part goes through an opaque register: otherwise the compiler hoists all NF * 4 slot pointers out of
         //  the persistent tile loop, keeps them live across the K loop and spills them -- 72 bytes of scratch per lane)
-        int lane4 = lane * 4, g4 = 4 * g;
-        asm volatile("" : "+v"(lane4));
-        asm volatile("" : "+v"(g4));                          // same for the column offsets of the scale / zero-point reads
+        const int lane4 = lane_e * 4, g4 = 4 * g_e;
         float *slot0 = (MODE == 0) ? nullptr
                                    : res_scratch + ((size_t)blockIdx.x * C::NW + wave) * (NF * 1024) + lane4;
 #pragma unroll
