@@ -387,9 +387,9 @@ def main():
         # How the GEMM kernel's duration is taken (HIP events on the launch stream, right after the timed region):
         #   * an event pair around ONE launch also times the launch path (marker packets either side of the dispatch:
         #     ~15 us on this stack -- the "kernel" would come out longer than the whole step), so a pair brackets a BATCH;
-        #   * a batch of GEMM launches alone runs the chip at a higher duty cycle than the product does (no pre-pass between
-        #     them: measured 155-167 us per launch in the rocprofv3 trace against 131-134 us inside real steps -- the loop is
-        #     power-limited), so the batches alternate the two kernels exactly as a step does;
+        #   * the batches alternate the two kernels exactly as a step does, and start right behind a wake-up loop: after
+        #     ANY idle gap of a few ms (the allocations below are one) the next ~15 ms of launches run slow (134 -> 169 us
+        #     per GEMM launch in the rocprofv3 trace; profiles/r02_duty_cycle_check.txt);
         #   * GEMM = (batch of [pre-pass, GEMM] pairs  -  batch of pre-passes) / launches.  Kernel-boundary gaps stay inside;
         #     the rocprofv3 average of the same kernel over the same command (profiles/) is the cross-check.
         BATCH = 8
