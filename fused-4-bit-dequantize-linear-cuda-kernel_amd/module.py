@@ -3,7 +3,7 @@ constructor ``(in_features, out_features)``, buffers ``packed_weights [N, K//2] 
 ``scales [N] float32``, ``zero_points [N] float32`` (state_dict keys and shapes unchanged),
 ``from_linear``, ``forward`` for 1-D / 2-D float32 input, ``extra_repr``.
 
-GPU tensors run the fused HIP kernels of libfql_int4.so (GEMV for B <= 4, INT8-limb MFMA GEMM
+GPU tensors run the fused HIP kernels of libfql_int4.so (GEMV for B <= 2, INT8-limb MFMA GEMM
 otherwise); if the extension is not built that raises -- there is no silent fallback.  CPU tensors
 take the un-fused dequantize-then-matmul, exactly as the reference's ``forward`` does.
 """

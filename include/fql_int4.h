@@ -77,7 +77,7 @@ extern "C" {
  *                         (v_mfma_scale_f32_32x32x64_f8f6f4, float32 accumulation) -- the "fp8 activations + INT4
  *                         weights" configuration of BASELINE.json configs[4].  ~2.7e-2 relative error on randn
  *                         activations (the format's, not the kernel's): outside the 1e-3 parity claim.  MFMA path
- *                         only (K % 32 == 0, 16-byte aligned weights, more than 4 rows for the linear op). */
+ *                         only (K % 32 == 0, 16-byte aligned weights, more than 2 rows for the linear op). */
 #define FQL_PRECISION_FP8 8
 
 /* Element types of activations and outputs for the dtype-generic entry points (fql_linear_fwd / fql_moe_fwd).
@@ -269,7 +269,7 @@ FQL_API int fql_gemm_i8_f32(const int8_t *limbs, const float *delta, const int32
  * Dtype-generic forms of fql_linear_fwd_f32 / fql_moe_fwd_f32 (float16 / bfloat16
  * activations and outputs, as the reference's MoE benches feed them).  Same arguments plus the element
  * types; (F32, F32) forwards to the float32 entry points.  16-bit I/O exists on the MFMA path only
- * (more than 4 rows, K % 32 == 0, 16-byte aligned packed weights): other shapes return FQL_ERR_DTYPE and
+ * (more than 2 rows, K % 32 == 0, 16-byte aligned packed weights): other shapes return FQL_ERR_DTYPE and
  * the caller converts.  fql_native_dtype_supported answers that question without launching anything.
  * ------------------------------------------------------------------------------------- */
 FQL_API int fql_native_dtype_supported(int rows, int E, int K, int N, int precision, const void *packed,
