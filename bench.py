@@ -435,7 +435,9 @@ def main():
                       "gemm_kernel_samples_dropped_as_host_stalls": nb - len(keep),
                       "gemm_kernel_launches_timed": n, "gemm_kernel_launches_per_event_pair": BATCH,
                       "gemm_kernel_ms_how": "HIP events: (batch of [pre-pass, GEMM] launch pairs - batch of pre-pass launches) / launches",
-                      "act_quant_ms_avg": pre_ms, "act_quant_ms_median": pre[nb // 2]})
+                      "act_quant_ms_avg": pre_ms, "act_quant_ms_median": pre[nb // 2],
+                      # the same two launches as a step, per pair, from the event-bracketed batches (median and min)
+                      "step_ms_median_events": both[nb // 2], "step_ms_min_events": both[0]})
         mfma_achieved = flops / (gemm_ms * 1e-3) / 1e12
         hbm_achieved = weight_bytes / (gemm_ms * 1e-3) / 1e9
         mfma_floor_ms = flops * limbs / (MFMA_I8_PEAK_TOPS * 1e12) * 1e3
