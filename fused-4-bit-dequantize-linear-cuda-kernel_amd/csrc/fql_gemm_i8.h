@@ -278,7 +278,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
         }
     };
 
-  int ev = 0;
+  int ev = 0; (void)ev;               // (only the FQL_TRACE build reads it)
   GemmTile cur = tile_params(blockIdx.x, lane);
   if constexpr (RES) {
       const ResidualProbe pb = residual_probe_issue(delta, T, cur, C::BM, lane, res_scratch != nullptr);

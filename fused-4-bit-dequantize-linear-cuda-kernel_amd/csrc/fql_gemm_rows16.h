@@ -261,7 +261,7 @@ const __amdgpu_buffer_rsrc_t rsBi = __builtin_amdgcn_make_buffer_rsrc(
         if (RES) d2bits = __builtin_amdgcn_raw_buffer_load_b32(rsD, (T + t) * 4, 0, 0);
     };
 
-    int ev = 0;
+    int ev = 0; (void)ev;
     FQL_STAMP(ev++);                                           // kernel entry
     GemmTile cur = tile_params(blockIdx.x);
     {

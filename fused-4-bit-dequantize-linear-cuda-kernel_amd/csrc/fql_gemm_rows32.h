@@ -225,7 +225,7 @@ const __amdgpu_buffer_rsrc_t rsBi = __builtin_amdgcn_make_buffer_rsrc(
         for (int l = 0; l < L; ++l) drow[1 + l] = __builtin_amdgcn_raw_buffer_load_b32(rsR, (L * tsel + l * T + t) * 4, 0, 0);
         if (RES) d2bits = __builtin_amdgcn_raw_buffer_load_b32(rsD, (T + t) * 4, 0, 0);
     };
-    int ev = 0;
+    int ev = 0; (void)ev;
     FQL_STAMP(ev++);                                          // 0: kernel entry (after n_real)
     Rows32Tile cur = tile_params(blockIdx.x);
     if constexpr (RES) cur.rp = tile_has_residual(delta, T, cur, C::BM, lane) && res_scratch != nullptr;
