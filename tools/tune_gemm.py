@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--static-too", action="store_true", help="also time every configuration without scratch: static tile order, no residual pass (ids 2000 + cfg)")
     ap.add_argument("--alt-lib", default="", help="a second build of libfql_int4.so: every configuration is also timed through it (ids 1000 + cfg)")
     ap.add_argument("--plain-too", action="store_true", help="also time every configuration with the plain BN-wide column tiling instead of the balanced tile widths (ids 3000 + cfg)")
+    ap.add_argument("--time-mismatched", action="store_true", help="also time configurations whose outputs differ (ablation builds)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _native.lib()
@@ -122,7 +123,7 @@ def main():
             ok[c] = same
             if not same:
                 print(f"cfg {c}: MISMATCH vs cfg {cfgs[0]} max|d|={(out - ref).abs().max().item():.3e}")
-    times = {c: [] for c in cfgs if ok.get(c)}
+    times = {c: [] for c in cfgs if ok.get(c) or (a.time_mismatched and c in ok)}
     out = torch.empty((T, N), dtype=torch.float32, device=dev)
     for r in range(a.rounds):
         for c in times:
