@@ -25,9 +25,10 @@
 #define FQL_W_AUX 2            // cache policy of the weight-stream loads: nt -- every byte is read once, by one wave
 #endif                         // (measured at 8 experts x 8 rows: 51.3 -> 47.4-48.8 us against the default policy)
 
-template <int L, int NF, int KG, int BDEPTH>
+template <int L, int NF, int KG, int BDEPTH, int NWAVES = 8>
 struct Rows16Cfg {
-    static constexpr int NW = 8;
+    static constexpr int NW = NWAVES;                         // 8: one workgroup per CU; 4: TWO independent workgroups per CU (one's
+                                                              // reduction / epilogue / start under the other's weight stream)
     static constexpr int NG = NW / KG;
     static constexpr int THREADS = 64 * NW;
     static constexpr int BM = 16;
@@ -51,8 +52,8 @@ struct Rows16Cfg {
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-template <int L, int NF, int KG, int BDEPTH>
-__global__ __launch_bounds__(512, 2) void gemm_i8_rows16_kernel(
+template <int L, int NF, int KG, int BDEPTH, int NWAVES = 8>
+__global__ __launch_bounds__(64 * NWAVES, 2) void gemm_i8_rows16_kernel(
     const int8_t *__restrict__ limbs, const float *__restrict__ delta,
     const int32_t *__restrict__ rowsum, const uint8_t *__restrict__ packed,
     const float *__restrict__ scales, const float *__restrict__ zps, void *__restrict__ out, int out_kind,
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(512, 2) void gemm_i8_rows16_kernel(
     const float *__restrict__ bias, int n_tiles_alt)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using C = Rows16Cfg<L, NF, KG, BDEPTH>;
+    using C = Rows16Cfg<L, NF, KG, BDEPTH, NWAVES>;
     constexpr bool RES = FQL_RES_ENABLED && (L >= 2);                           // residual limb set for heavy-tailed rows (fql_gemm_i8.h)
     constexpr int NG = C::NG, BD = C::BD;
     constexpr int OOB = 0x7fff0000;

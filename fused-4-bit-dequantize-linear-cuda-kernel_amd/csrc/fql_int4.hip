@@ -159,8 +159,15 @@ constexpr int FQL_NUM_ROWS32 = 8;
     S(7, 3, 8, 1)              /* 16 x  48, one weight stage in flight */ \
     S(8, 2, 8, 2)              /* 16 x  32 */
 constexpr int FQL_NUM_ROWS16 = 9;
+// the same kernel as 4-wave workgroups, two per CU.  ids 220 + i.  S4(i, NF, KG, weight stages in flight)
+#define FQL_ROWS16_W4_LIST(S4)                                                                                     \
+    S4(0, 4, 4, 1)             /* 16 x  64, K split 4 ways */ \
+    S4(1, 4, 4, 2)             /* 16 x  64, two weight stages in flight */ \
+    S4(2, 4, 2, 1)             /* 16 x 128, K split 2 ways */ \
+    S4(3, 8, 4, 1)             /* 16 x 128, 8 fragments per wave */
+constexpr int FQL_NUM_ROWS16_W4 = 4;
 inline bool valid_cfg(int cfg) { return (cfg >= 0 && cfg < FQL_NUM_CFG) || (cfg >= 100 && cfg < 100 + FQL_NUM_ROWS32) ||
-           (cfg >= 200 && cfg < 200 + FQL_NUM_ROWS16);
+           (cfg >= 200 && cfg < 200 + FQL_NUM_ROWS16) || (cfg >= 220 && cfg < 220 + FQL_NUM_ROWS16_W4);
 }
 
 // The MFMA path addresses its operands through 32-bit buffer offsets.
@@ -316,19 +323,19 @@ int launch_rows32_cfg(const Workspace &w, const uint8_t *packed, const float *sc
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
-template <int L, int NF, int KG, int BDEPTH>
+template <int L, int NF, int KG, int BDEPTH, int NWAVES = 8>
 int launch_rows16_cfg(const Workspace &w, const uint8_t *packed, const float *scales, const float *zps, void *out,
                       int out_dtype, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT,
                       int N, hipStream_t st)
 {
-    using C = Rows16Cfg<L, NF, KG, BDEPTH>;
-    auto kern = gemm_i8_rows16_kernel<L, NF, KG, BDEPTH>;
+    using C = Rows16Cfg<L, NF, KG, BDEPTH, NWAVES>;
+    auto kern = gemm_i8_rows16_kernel<L, NF, KG, BDEPTH, NWAVES>;
     static PerDeviceFlag attr;
     if (!ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), C::LDS_BYTES)) return FQL_ERR_LAUNCH;
     (void)hipGetLastError();                                 // a stale error of another library must not read as ours
     const int n_tiles = (N + C::BN - 1) / C::BN;
     const int m_slots = (tpe == nullptr) ? (T + C::BM - 1) / C::BM : T / C::BM + E;
-    const int cus = compute_units();
+    const int cus = compute_units() * (8 / C::NW);          // persistent: one 8-wave or two 4-wave workgroups per CU
     const int groups = (tpe == nullptr) ? 1 : E;
     const long long m_even = (long long)groups * (((T + groups - 1) / groups + C::BM - 1) / C::BM);   // row blocks if evenly routed
     int n_alt = balanced_n_tiles(N, C::BN / 16, m_even, cus, 16, 2, 1);     // uneven column tiles (fql_gemm_rows16.h)
@@ -365,6 +372,12 @@ int launch_gemm(int cfg, const Workspace &w, const uint8_t *packed, const float 
                                                 st);
         FQL_ROWS16_LIST(S)
 #undef S
+#define S4(i, nf, kg, bd)                                                                                          \
+    case 220 + i:                                                                                                 \
+        return launch_rows16_cfg<L, nf, kg, bd, 4>(w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, \
+                                                   N, st);
+        FQL_ROWS16_W4_LIST(S4)
+#undef S4
     default: return FQL_ERR_BAD_SHAPE;
     }
 }

@@ -71,8 +71,40 @@ static double time_ms(F launch)
     return ms / 5;
 }
 
-int main()
+// one decode-size launch: 8 x 11008 rows of 2048 B = 180 MB, a different buffer every launch (4 x 180 MB > the 256 MB
+// Infinity Cache), events around 8 launches: what a pure weight stream of that size costs per launch, launch included
+static void decode_size()
 {
+    const int K2 = 2048, n_rows = 8 * 11008;
+    const size_t bytes = (size_t)n_rows * K2;
+    char *buf[4]; int *sink;
+    for (auto &b : buf) { hipMalloc(&b, bytes); hipMemset(b, 1, bytes); }
+    hipMalloc(&sink, 2048 * 512 * 4);
+    printf("== decode size: %d rows x %d B = %.1f MB per launch, 4 buffers rotated\n", n_rows, K2, bytes / 1e6);
+    auto run = [&](const char *name, auto launch) {
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int i = 0; i < 8; ++i) launch(buf[i & 3]);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int i = 0; i < 8; ++i) launch(buf[i & 3]);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("%-44s %8.1f us per launch  %6.2f TB/s\n", name, ms / 8 * 1e3, bytes / (ms / 8) / 1e9);
+    };
+    run("linear U=2, 256 workgroups", [&](char *b) { hipLaunchKernelGGL((linear_k<2>), dim3(256), dim3(512), 0, 0, b, bytes, sink); });
+    run("tile 128 rows x 128 B, U=1, 256 workgroups", [&](char *b) { hipLaunchKernelGGL((tile_k<128, 128, 1>), dim3(256), dim3(512), 0, 0, b, n_rows, K2, sink); });
+    run("tile 128 rows x 128 B, U=2, 256 workgroups", [&](char *b) { hipLaunchKernelGGL((tile_k<128, 128, 2>), dim3(256), dim3(512), 0, 0, b, n_rows, K2, sink); });
+    run("tile 128 rows x 128 B, U=4, 256 workgroups", [&](char *b) { hipLaunchKernelGGL((tile_k<128, 128, 4>), dim3(256), dim3(512), 0, 0, b, n_rows, K2, sink); });
+    run("tile 128 rows x 128 B, U=2, 512 workgroups", [&](char *b) { hipLaunchKernelGGL((tile_k<128, 128, 2>), dim3(512), dim3(512), 0, 0, b, n_rows, K2, sink); });
+    run("tile 128 rows x 128 B, U=2, 1024 workgroups", [&](char *b) { hipLaunchKernelGGL((tile_k<128, 128, 2>), dim3(1024), dim3(512), 0, 0, b, n_rows, K2, sink); });
+    for (auto &b : buf) hipFree(b);
+    hipFree(sink);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 1 && argv[1][0] == 'd') { decode_size(); return 0; }
     for (int K2 : {2048, 3584}) {
     const int n_rows = (K2 == 2048 ? 32 : 64) * 18432;
     const size_t bytes = (size_t)n_rows * K2;
