@@ -332,9 +332,15 @@ def main():
     # Before the W warm-up steps: keep the GPU busy with the same call for ~0.25 s.  The workload construction above ends
     # with host-side work, the device drops into a low-power state meanwhile, and climbing out of it took 30-70 ms on the
     # MI355X boxes of this pool -- longer than W short steps, so it used to land inside the timed region.
-    t_wake = time.perf_counter()
-    while time.perf_counter() - t_wake < 0.25:
-        for _ in range(10):
+    if world == 1:
+        t_wake = time.perf_counter()
+        while time.perf_counter() - t_wake < 0.25:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+    else:
+        # every rank must make the SAME number of (collective) steps: a fixed count, never a wall-clock loop
+        for _ in range(100):
             step()
         torch.cuda.synchronize()
     for _ in range(a.warmup):
