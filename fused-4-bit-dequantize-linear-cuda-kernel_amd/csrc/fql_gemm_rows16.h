@@ -335,6 +335,7 @@ const __amdgpu_buffer_rsrc_t rsBi = __builtin_amdgcn_make_buffer_rsrc(
         // ---- stage boundary: park this stage's weights, then issue EVERYTHING the next stage(s) need
 #pragma unroll
         for (int i = 0; i < C::PIECES; ++i) *reinterpret_cast<v4i *>(slab + ((i & 1) ? wB1 : wB0) + i * 1024) = bst[u][i];
+        FQL_STAMP_FINE(ev++);                                  // this stage's weights have arrived and are parked
         {   // order matters (loads complete in order): the L2-resident activations of the NEXT stage first, the HBM
             // weights of the stage BD ahead last, so the next boundary's wait for the activations does not include
             // the youngest HBM loads
@@ -345,6 +346,7 @@ const __amdgpu_buffer_rsrc_t rsBi = __builtin_amdgcn_make_buffer_rsrc(
             const bool here = s + BD < SP;
             issue_weights(here ? rs_cur : rs_nxt, here ? w_soff(cur, s + BD) : w_soff(nxt, s + BD - SP), u, here ? nfw_cur : nfw_nxt);
         }
+        FQL_STAMP_FINE(ev++);                                  // next loads issued
         // ---- 4 MFMA steps of 64 k: LDS reads, unpack, matrix cores; no memory instruction in here
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
@@ -362,6 +364,7 @@ const __amdgpu_buffer_rsrc_t rsBi = __builtin_amdgcn_make_buffer_rsrc(
 #pragma unroll
                 for (int j = 0; j < NF; ++j)
                     acc[l][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wfr[j], afr[apar][st][l], acc[l][j], 0, 0, 0);
+            if (st == 0) FQL_STAMP_FINE(ev++);                  // first step's operands were there (activations arrived)
         }
         __builtin_amdgcn_sched_barrier(0);
       }

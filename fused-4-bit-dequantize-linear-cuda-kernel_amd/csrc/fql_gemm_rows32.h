@@ -49,6 +49,11 @@ __device__ unsigned long long fql_trace_buf[8 * 64];         // [block < 8][even
 #else
 #define FQL_STAMP(i) do { } while (0)
 #endif
+#if defined(FQL_TRACE) && FQL_TRACE >= 2                      // finer stamps inside a stage (rows16)
+#define FQL_STAMP_FINE(i) FQL_STAMP(i)
+#else
+#define FQL_STAMP_FINE(i) do { } while (0)
+#endif
 
 typedef GemmTile Rows32Tile;   // wave-uniform description of one visit of a 32-row x BN tile (fql_gemm_i8.h)
 
