@@ -57,9 +57,9 @@ __global__ __launch_bounds__(256) void fused_rows_kernel(
 // Per-GROUP scales and zero points along K (not in the reference, whose quantisation is per row:
 // python/quantize.py:73-80): scales / zps are [E][N][K / group] and
 //   out[t][n] = sum_k x[t][k] * (q[n][k] - zp[n][k / group]) * scale[n][k / group]        (float32 FMA, as above).
-// Functional path for GPTQ / AWQ-style checkpoints: the same one-wave-per-output-row kernel, the group's two constants
-// looked up per packed byte (L1 hits).  Not a fast path: the integer MFMA kernels need ONE scale per output row to
-// keep their accumulators integer across K (a float flush per group is VALU-bound next to the MFMAs).
+// GPTQ / AWQ-style checkpoints: the same one-wave-per-output-row kernel, the group's two constants looked up per packed
+// byte (L1 hits).  Takes the calls with fewer than 4 rows per group and the shapes fql_group.h (the float32
+// matrix-core kernel for batches) does not: K % 64 != 0, group % 32 != 0, unaligned bases.
 template <int RB>
 __global__ __launch_bounds__(256) void fused_rows_group_kernel(
     const float *__restrict__ x, const uint8_t *__restrict__ packed, const float *__restrict__ scales,

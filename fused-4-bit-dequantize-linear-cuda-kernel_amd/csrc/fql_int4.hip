@@ -10,6 +10,7 @@
 #include "fql_gemm_rows32.h"
 #include "fql_gemm_rows16.h"
 #include "fql_gemv.h"
+#include "fql_group.h"
 #include "fql_generic.h"
 #include "fql_quantize.h"
 #include "fql_routing.h"
@@ -20,6 +21,7 @@ namespace {
 // product call in a hipGraph: GEMV 9.3 / 12.1 / 19.7 us at B = 1 / 2 / 3, MFMA path 16.4 / 16.5 / 16.1 us at
 // B = 2 / 3 / 4 and 16.2-16.5 us at B = 5..16: profiles/r02_linear_batch_sweep.txt).  Tuning hook below.
 int g_gemv_max_rows = 2;
+int g_group_mfma = 1;                  // per-group scales: the float32 matrix-core kernel for batches (A/B hook below)
 int g_act_single_rows = 512;          // pre-pass: one row per workgroup up to this many padded rows (tuning hook below)
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -779,8 +781,21 @@ static int group_entry(const float *x, const uint8_t *packed, const float *scale
         hipLaunchKernelGGL(zero_uncovered_rows_kernel, dim3(T), dim3(256), 0, st, out, tpe, offs, E, T, N);
         if (hipGetLastError() != hipSuccess) return FQL_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL((fused_rows_group_kernel<4>), dim3((N + 3) / 4, E), dim3(256), 0, st, x, packed, scales, zps, out,
-                       tpe, offs, T, K, N, group, bias);
+    // batches: the float32 matrix-core kernel (fql_group.h); a few rows per group: one wave per output row (fql_generic.h)
+    const int groups = tpe == nullptr ? 1 : E;
+    const bool batch = g_group_mfma && (T + groups - 1) / groups >= 4 && K % 64 == 0 && group % 32 == 0 &&
+                       (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(packed) % 16 == 0) &&
+                       (T + 63) / 64 <= 65535;
+    const int per = (T + groups - 1) / groups;
+    if (batch && per <= 128 && K % 256 == 0)                     // few rows per group: 32 x 32 blocks, K split over the waves
+        hipLaunchKernelGGL(group_mfma_kernel<true>, dim3((N + 31) / 32, (T + 31) / 32, E), dim3(256), 0, st, x, packed, scales,
+                           zps, out, tpe, offs, T, K, N, group, bias);
+    else if (batch)
+        hipLaunchKernelGGL(group_mfma_kernel<false>, dim3((N + 63) / 64, (T + 63) / 64, E), dim3(256), 0, st, x, packed, scales,
+                           zps, out, tpe, offs, T, K, N, group, bias);
+    else
+        hipLaunchKernelGGL((fused_rows_group_kernel<4>), dim3((N + 3) / 4, E), dim3(256), 0, st, x, packed, scales, zps, out,
+                           tpe, offs, T, K, N, group, bias);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
@@ -1015,6 +1030,7 @@ FQL_API int fql_debug_trace(unsigned long long *dst)
 #endif
 FQL_API int fql_tune_set_act_single_rows(int rows) { const int old = g_act_single_rows; if (rows >= 0) g_act_single_rows = rows; return old; }
 FQL_API int fql_tune_set_balance_tiles(int on) { const int old = g_balance_tiles; g_balance_tiles = on ? 1 : 0; return old; }
+FQL_API int fql_tune_set_group_mfma(int on) { const int old = g_group_mfma; g_group_mfma = on ? 1 : 0; return old; }
 FQL_API int fql_tune_set_gemv_max_rows(int rows) { const int old = g_gemv_max_rows; if (rows >= 0 && rows <= 4) g_gemv_max_rows = rows; return old; }
 FQL_API int fql_tune_num_configs(void) { return FQL_NUM_CFG; }
 FQL_API int fql_tune_num_rows32_configs(void) { return FQL_NUM_ROWS32; }

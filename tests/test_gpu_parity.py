@@ -738,9 +738,13 @@ def test_balanced_column_tiles_ragged_n(fq):
 
 
 # ------------------------------------------------------------------------------ per-group scales along K
-@pytest.mark.parametrize("B,N,K,group", [(1, 64, 256, 64), (7, 200, 512, 128), (40, 96, 1024, 32), (3, 33, 96, 2)])
+@pytest.mark.parametrize("B,N,K,group", [(1, 64, 256, 64), (7, 200, 512, 128), (40, 96, 1024, 32), (3, 33, 96, 2),
+                                         (200, 100, 192, 64), (300, 130, 512, 128), (130, 64, 256, 32), (5, 40, 64, 32),
+                                         (16, 72, 128, 16)])
 def test_per_group_scales_linear(fq, B, N, K, group):
-    """Not in the reference (per-row only): checked against the float64 dequantize-then-matmul with per-group constants."""
+    """Not in the reference (per-row only): checked against the float64 dequantize-then-matmul with per-group constants.
+    Shapes cover the one-wave-per-row kernel (few rows, odd groups) and both forms of the float32 matrix-core kernel
+    (csrc/fql_group.h: 32 x 32 blocks with K split over the waves, 64 x 64 tiles), ragged in rows and columns."""
     from fused_int4_amd import ops
     rng = np.random.default_rng(B + K)
     w = rng.standard_normal((N, K)).astype(np.float32)
@@ -759,11 +763,12 @@ def test_per_group_scales_linear(fq, B, N, K, group):
     assert torch.allclose(m(xt.cuda()).cpu(), m.cpu()(xt), atol=1e-3, rtol=1e-5)
 
 
-def test_per_group_scales_grouped_moe(fq):
+@pytest.mark.parametrize("E,N,K,group,counts", [(4, 96, 256, 64, [9, 0, 17, 5]), (4, 136, 512, 128, [150, 0, 40, 3]),
+                                                (3, 70, 192, 32, [260, 1, 66])])
+def test_per_group_scales_grouped_moe(fq, E, N, K, group, counts):
     from fused_int4_amd import ops
     rng = np.random.default_rng(5)
-    E, N, K, group = 4, 96, 256, 64
-    counts = np.array([9, 0, 17, 5], np.int32)
+    counts = np.array(counts, np.int32)
     offs = (np.cumsum(counts) - counts).astype(np.int32)
     T = int(counts.sum()) + 2
     q = [O.quantize_weights_grouped(rng.standard_normal((N, K)).astype(np.float32), group) for _ in range(E)]
