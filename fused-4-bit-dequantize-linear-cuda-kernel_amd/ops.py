@@ -75,7 +75,7 @@ def linear_forward(input, packed_weights, scales, zero_points, precision="defaul
     N, packed_dim = packed_weights.shape
     if packed_dim != K // 2 or K % 2 != 0:
         raise RuntimeError("packed_weights dim 1 must be input_dim / 2")
-    if scales.dim() == 2 and scales.shape[1] > 1:           # per-group scales along K (functional path)
+    if scales.dim() == 2 and scales.shape[1] > 1:           # per-group scales along K (float32 contraction: include/fql_int4.h)
         out = _linear_group_forward(input, packed_weights, scales, zero_points, bias)
         return out.squeeze(0) if squeeze else out
     # not checked by the reference (silent UB there); checked here
@@ -137,7 +137,7 @@ def _linear_group_forward(input, packed_weights, scales, zero_points, bias):
 
 def moe_group_forward(packed_weights, scales, zero_points, inputs, tokens_per_expert, input_offsets):
     """Grouped per-expert INT4 GEMM with per-GROUP scales along K: ``scales`` / ``zero_points`` [E, N, K / group_size].
-    Functional path (include/fql_int4.h); rows no expert covers are zero."""
+    Float32 contraction (include/fql_int4.h); rows no expert covers are zero."""
     if not inputs.is_cuda or inputs.dtype != torch.float32 or inputs.dim() != 2 or packed_weights.dim() != 3:
         raise RuntimeError("inputs must be a CUDA float32 [T, K] tensor and packed_weights [E, N, K/2]")
     E, N, K2 = packed_weights.shape

@@ -179,8 +179,11 @@ FQL_API int fql_linear_fwd_f8(const uint8_t *x_e4m3, const float *act_scales, co
  *   out[t][n] = sum_k x[t][k] * (q[n][k] - zps[n][k / group_size]) * scales[n][k / group_size]   (+ bias[n])
  *
  *   scales, zps [N][K / group_size] float32 ([E][N][K / group_size] for the grouped form); group_size even, divides K.
- * A FUNCTIONAL path (one wave per output row, float32 FMA), any shape, no workspace: the integer MFMA kernels need a
- * single scale per output row.  Per-row quantisation (group_size == K) stays on the fast entry points above.
+ * Any shape, no workspace.  The weights are dequantised in registers, (q - zp) * scale as the reference kernel does per
+ * element, and the contraction is float32: on the float32 matrix-core instruction for 4 or more rows per group with
+ * K % 64 == 0, group_size % 32 == 0 and 16-byte aligned bases, one wave per output row (float32 FMA) otherwise.  The
+ * integer MFMA kernels need a single scale per output row: per-row quantisation (group_size == K) stays on the faster
+ * entry points above.
  * ------------------------------------------------------------------------------------- */
 FQL_API int fql_linear_group_fwd_f32(const float *x, const uint8_t *packed, const float *scales,
                                      const float *zps, const float *bias, float *out, int B, int K, int N,
