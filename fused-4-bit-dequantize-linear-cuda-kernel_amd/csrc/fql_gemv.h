@@ -19,10 +19,14 @@
 #define GEMV_ROWS 4          // weight rows in flight per wave
 #define GEMV_SEG 36          // floats per padded 32-float LDS segment
 
-template <int B>
+// GROUPED: per-GROUP scales along K (scales / zps [N][K / group], group % 32 == 0): a lane's 32 k of
+// a chunk share one group, so the chunk's dot product and the chunk's sum of x are folded with that group's constants,
+//   acc += scale[n][g] * (sum_k q x - zp[n][g] * sum_k x),
+// instead of once per row at the end.
+template <int B, bool GROUPED = false>
 __global__ __launch_bounds__(256) void gemv_kernel(
     const float *__restrict__ x, const uint8_t *__restrict__ packed, const float *__restrict__ scales,
-    const float *__restrict__ zps, float *__restrict__ out, int K, int N, const float *__restrict__ bias)
+    const float *__restrict__ zps, float *__restrict__ out, int K, int N, const float *__restrict__ bias, int group = 0)
 {
     extern __shared__ __attribute__((aligned(16))) float xs[];      // [B][K/32][36] + sums
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,16 +74,31 @@ __global__ __launch_bounds__(256) void gemv_kernel(
                 const int n = (n0 + r < N) ? n0 + r : N - 1;
                 w[r] = *reinterpret_cast<const uint4 *>(packed + (size_t)n * K2 + (size_t)j * 16);
             }
+            float gsc[GEMV_ROWS], gzp[GEMV_ROWS];
+            if constexpr (GROUPED) {
+                const int G = K / group, g = (32 * j) / group;
+#pragma unroll
+                for (int r = 0; r < GEMV_ROWS; ++r) {
+                    const int n = (n0 + r < N) ? n0 + r : N - 1;
+                    gsc[r] = scales[(size_t)n * G + g];
+                    gzp[r] = zps[(size_t)n * G + g];
+                }
+            }
 #pragma unroll
             for (int b = 0; b < B; ++b) {
                 const float *xb = xs + ((size_t)b * segs + j) * GEMV_SEG;
                 v4f xv[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) xv[i] = *reinterpret_cast<const v4f *>(xb + 4 * i);
+                float xsum = 0.0f;
+                if constexpr (GROUPED) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) xsum += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
+                }
 #pragma unroll
                 for (int r = 0; r < GEMV_ROWS; ++r) {
                     const uint32_t ww[4] = {w[r].x, w[r].y, w[r].z, w[r].w};
-                    float a = acc[r][b];
+                    float a = GROUPED ? 0.0f : acc[r][b];
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {           // dword d holds k = 8d .. 8d+7
                         uint32_t lo, hi;
@@ -93,20 +112,22 @@ __global__ __launch_bounds__(256) void gemv_kernel(
                             a = fmaf(q1, xv[(k + 1) >> 2][(k + 1) & 3], a);
                         }
                     }
-                    acc[r][b] = a;
+                    if constexpr (GROUPED) acc[r][b] = fmaf(gsc[r], fmaf(-gzp[r], xsum, a), acc[r][b]);
+                    else acc[r][b] = a;
                 }
             }
         }
 #pragma unroll
         for (int r = 0; r < GEMV_ROWS; ++r) {
             const int n = n0 + r;
-            const float sc = (n < N) ? scales[n] : 0.0f;
-            const float zp = (n < N) ? zps[n] : 0.0f;
+            const float sc = (!GROUPED && n < N) ? scales[n] : 0.0f;
+            const float zp = (!GROUPED && n < N) ? zps[n] : 0.0f;
 #pragma unroll
             for (int b = 0; b < B; ++b) {
                 const float dot = wave_sum(acc[r][b]);
                 if (lane == 0 && n < N) {
-                    const float v = sc * fmaf(-zp, sx[b], dot);
+#pragma clang fp contract(off)                               // the bias is ONE float32 add after the rounded un-biased result
+                    const float v = GROUPED ? dot : sc * fmaf(-zp, sx[b], dot);
                     out[(size_t)b * N + n] = bias != nullptr ? v + bias[n] : v;
                 }
             }

@@ -513,21 +513,21 @@ int run_generic(const float *x, const uint8_t *packed, const float *scales, cons
 
 size_t gemv_lds_bytes(int B, int K) { return ((size_t)B * (K >> 5) * GEMV_SEG + (size_t)B * 4) * sizeof(float); }
 
-template <int B>
+template <int B, bool GROUPED = false>
 int launch_gemv(const float *x, const uint8_t *packed, const float *scales, const float *zps, float *out,
-                int K, int N, hipStream_t st, const float *bias)
+                int K, int N, hipStream_t st, const float *bias, int group = 0)
 {
     const int groups = (N + GEMV_ROWS - 1) / GEMV_ROWS;
     int blocks = (groups + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     const size_t lds = gemv_lds_bytes(B, K);
     if (lds > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemv_kernel<B>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&gemv_kernel<B, GROUPED>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return FQL_ERR_LAUNCH;
     }
     (void)hipGetLastError();
-    hipLaunchKernelGGL((gemv_kernel<B>), dim3(blocks), dim3(256), lds, st, x, packed, scales, zps, out, K, N, bias);
+    hipLaunchKernelGGL((gemv_kernel<B, GROUPED>), dim3(blocks), dim3(256), lds, st, x, packed, scales, zps, out, K, N, bias, group);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
@@ -787,6 +787,14 @@ static int group_entry(const float *x, const uint8_t *packed, const float *scale
                        (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (reinterpret_cast<uintptr_t>(packed) % 16 == 0) &&
                        (T + 63) / 64 <= 65535;
     const int per = (T + groups - 1) / groups;
+    if (tpe == nullptr && T <= 3 && K % 32 == 0 && group % 32 == 0 && aligned16(packed) && aligned16(x) &&
+        gemv_lds_bytes(T, K) <= 150 * 1024) {                     // a few rows of one matrix: the GEMV kernel, constants per group
+        switch (T) {
+        case 1: return launch_gemv<1, true>(x, packed, scales, zps, out, K, N, st, bias, group);
+        case 2: return launch_gemv<2, true>(x, packed, scales, zps, out, K, N, st, bias, group);
+        default: return launch_gemv<3, true>(x, packed, scales, zps, out, K, N, st, bias, group);
+        }
+    }
     if (batch && per <= 128 && K % 256 == 0)                     // few rows per group: 32 x 32 blocks, K split over the waves
         hipLaunchKernelGGL(group_mfma_kernel<true>, dim3((N + 31) / 32, (T + 31) / 32, E), dim3(256), 0, st, x, packed, scales,
                            zps, out, tpe, offs, T, K, N, group, bias);

@@ -740,10 +740,10 @@ def test_balanced_column_tiles_ragged_n(fq):
 # ------------------------------------------------------------------------------ per-group scales along K
 @pytest.mark.parametrize("B,N,K,group", [(1, 64, 256, 64), (7, 200, 512, 128), (40, 96, 1024, 32), (3, 33, 96, 2),
                                          (200, 100, 192, 64), (300, 130, 512, 128), (130, 64, 256, 32), (5, 40, 64, 32),
-                                         (16, 72, 128, 16)])
+                                         (16, 72, 128, 16), (2, 100, 512, 128), (3, 72, 256, 32)])
 def test_per_group_scales_linear(fq, B, N, K, group):
     """Not in the reference (per-row only): checked against the float64 dequantize-then-matmul with per-group constants.
-    Shapes cover the one-wave-per-row kernel (few rows, odd groups) and both forms of the float32 matrix-core kernel
+    Shapes cover the one-wave-per-row kernel (odd groups), the GEMV kernel with per-group constants (<= 3 rows) and both forms of the float32 matrix-core kernel
     (csrc/fql_group.h: 32 x 32 blocks with K split over the waves, 64 x 64 tiles), ragged in rows and columns."""
     from fused_int4_amd import ops
     rng = np.random.default_rng(B + K)
