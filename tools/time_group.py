@@ -43,3 +43,23 @@ for B in (1, 2, 3, 4, 16, 64, 512):
     t_bias = timed(lambda s: ops.linear_forward(x, *s, bias=bias), row_sets)
     t_grp = timed(lambda s: ops.linear_forward(x, *s), grp_sets)
     print(f"linear {K}->{N} B={B:4d}: per-row {t_row:8.1f} us | per-row + bias {t_bias:8.1f} us | per-group (g={G}) {t_grp:8.1f} us")
+
+# grouped MoE, 8 experts (cold: 4 weight sets of 180 MB)
+E = 8
+moe_row, moe_grp = [], []
+for i in range(4):
+    P, S, Z, Pg, Sg, Zg = [], [], [], [], [], []
+    for e in range(E):
+        w = torch.randn(N, K, device=dev, generator=g) * 0.02
+        p, s, z = fq.quantize_weights(w); P.append(p); S.append(s); Z.append(z)
+        p, s, z = fq.quantize_weights(w, group_size=G); Pg.append(p); Sg.append(s); Zg.append(z)
+    moe_row.append((torch.stack(P), torch.stack(S), torch.stack(Z)))
+    moe_grp.append((torch.stack(Pg), torch.stack(Sg), torch.stack(Zg)))
+for m in (8, 128):
+    T = E * m
+    x = torch.randn(T, K, device=dev, generator=g)
+    tpe = torch.full((E,), m, dtype=torch.int32, device=dev)
+    offs = torch.arange(E, dtype=torch.int32, device=dev) * m
+    t_row = timed(lambda s: ops.moe_forward(s[0], s[1], s[2], x, None, tpe, offs), moe_row)
+    t_grp = timed(lambda s: ops.moe_group_forward(s[0], s[1], s[2], x, tpe, offs), moe_grp)
+    print(f"moe 8 x {K}->{N}, {m} rows per expert: per-row {t_row:8.1f} us | per-group (g={G}) {t_grp:8.1f} us")
