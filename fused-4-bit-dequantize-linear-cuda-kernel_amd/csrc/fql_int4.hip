@@ -796,11 +796,14 @@ static int group_entry(const float *x, const uint8_t *packed, const float *scale
         }
     }
     if (batch && per <= 128 && K % 256 == 0)                     // few rows per group: 32 x 32 blocks, K split over the waves
-        hipLaunchKernelGGL(group_mfma_kernel<true>, dim3((N + 31) / 32, (T + 31) / 32, E), dim3(256), 0, st, x, packed, scales,
+        hipLaunchKernelGGL((group_mfma_kernel<true, 1>), dim3((N + 31) / 32, (T + 31) / 32, E), dim3(256), 0, st, x, packed, scales,
                            zps, out, tpe, offs, T, K, N, group, bias);
+    else if (batch && (long long)((N + 127) / 128) * ((per + 63) / 64) * groups >= 2LL * compute_units())
+        hipLaunchKernelGGL((group_mfma_kernel<false, 2>), dim3((N + 127) / 128, (T + 63) / 64, E), dim3(256), 0, st, x, packed,
+                           scales, zps, out, tpe, offs, T, K, N, group, bias);
     else if (batch)
-        hipLaunchKernelGGL(group_mfma_kernel<false>, dim3((N + 63) / 64, (T + 63) / 64, E), dim3(256), 0, st, x, packed, scales,
-                           zps, out, tpe, offs, T, K, N, group, bias);
+        hipLaunchKernelGGL((group_mfma_kernel<false, 1>), dim3((N + 63) / 64, (T + 63) / 64, E), dim3(256), 0, st, x, packed,
+                           scales, zps, out, tpe, offs, T, K, N, group, bias);
     else
         hipLaunchKernelGGL((fused_rows_group_kernel<4>), dim3((N + 3) / 4, E), dim3(256), 0, st, x, packed, scales, zps, out,
                            tpe, offs, T, K, N, group, bias);
