@@ -35,6 +35,9 @@ _SYMBOLS = {
                                 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "fql_linear_group_fwd_f32": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fql_moe_group_fwd_f32": (ctypes.c_int, [ctypes.c_void_p] * 7 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    "fql_group_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 6),
+    "fql_linear_group_ws_fwd_f32": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "fql_moe_group_ws_fwd_f32": (ctypes.c_int, [ctypes.c_void_p] * 7 + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "fql_moe_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 5),
     "fql_moe_fwd_f32": (ctypes.c_int, [ctypes.c_void_p] * 7 + [ctypes.c_int] * 5
                         + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),

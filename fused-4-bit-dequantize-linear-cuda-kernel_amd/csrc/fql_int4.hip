@@ -11,6 +11,7 @@
 #include "fql_gemm_rows16.h"
 #include "fql_gemv.h"
 #include "fql_group.h"
+#include "fql_group_i8.h"
 #include "fql_generic.h"
 #include "fql_quantize.h"
 #include "fql_routing.h"
@@ -21,6 +22,7 @@ namespace {
 // product call in a hipGraph: GEMV 9.3 / 12.1 / 19.7 us at B = 1 / 2 / 3, MFMA path 16.4 / 16.5 / 16.1 us at
 // B = 2 / 3 / 4 and 16.2-16.5 us at B = 5..16: profiles/r02_linear_batch_sweep.txt).  Tuning hook below.
 int g_gemv_max_rows = 2;
+int g_group_i8 = 1;                    // per-group scales: the INT8 matrix-core kernel where eligible (A/B hook below)
 int g_group_mfma = 1;                  // per-group scales: the float32 matrix-core kernel for batches (A/B hook below)
 int g_act_single_rows = 512;          // pre-pass: one row per workgroup up to this many padded rows (tuning hook below)
 
@@ -810,6 +812,76 @@ static int group_entry(const float *x, const uint8_t *packed, const float *scale
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
+// ---- per-group scales on the INTEGER matrix cores (csrc/fql_group_i8.h): needs the activation workspace of the per-row
+//      path plus a [E][G][N] transpose of the scales and zero points
+static bool group_i8_eligible(int L, int E, int T, int K, int N, int group, const void *x, const void *packed, bool grouped)
+{
+    const int groups = grouped ? E : 1;
+    return g_group_i8 && L >= 1 && L <= 3 && K % FQL_KB == 0 && group % 64 == 0 && K % group == 0 && (T + groups - 1) / groups >= 48 &&
+           aligned16(packed) && (reinterpret_cast<uintptr_t>(x) % 4 == 0) && N >= 4 && (T + FQL_MB - 1) / FQL_MB + 1 <= 65535 && E <= 65535;
+}
+
+size_t fql_group_workspace_bytes(int E, int T, int K, int N, int group_size, int precision)
+{
+    const int L = limbs_of(precision);
+    if (L < 1 || is_f8(precision) || E <= 0 || T <= 0 || K <= 0 || N <= 0 || group_size <= 0 || K % group_size != 0 || (K % 32) != 0) return 0;
+    const Workspace w = carve(nullptr, L, T, E, padded_k(K), has_residual(L, false));
+    return round16(w.bytes) + 2 * round16((size_t)E * N * (K / group_size) * sizeof(float));
+}
+
+static int group_ws_entry(const float *x, const uint8_t *packed, const float *scales, const float *zps, const float *bias,
+                          float *out, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int N, int group,
+                          int precision, void *workspace, size_t workspace_bytes, void *stream)
+{
+    const int L = limbs_of(precision);
+    if (L < 0 || is_f8(precision)) return FQL_ERR_BAD_PRECISION;
+    if (E <= 0 || T < 0 || K < 0 || N < 0) return FQL_ERR_BAD_SHAPE;
+    if (group <= 0 || K <= 0 || K % group != 0) return (K == 0) ? group_entry(x, packed, scales, zps, bias, out, tpe, offs, E, T, K, N, group > 0 ? group : 2, stream) : FQL_ERR_BAD_SHAPE;
+    const bool ok = workspace != nullptr && aligned16(workspace) && x && packed && scales && zps && out && T > 0 && N > 0 &&
+                    ((tpe == nullptr) == (offs == nullptr)) && (tpe != nullptr || E == 1) &&
+                    group_i8_eligible(L, E, T, K, N, group, x, packed, tpe != nullptr) &&
+                    workspace_bytes >= fql_group_workspace_bytes(E, T, K, N, group, precision);
+    if (!ok) return group_entry(x, packed, scales, zps, bias, out, tpe, offs, E, T, K, N, group, stream);   // float32 paths (and their checks)
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int Kp = padded_k(K), MBT = row_blocks(T, E), G = K / group;
+    Workspace w = carve(workspace, L, T, E, Kp, has_residual(L, false));
+    float *st_t = reinterpret_cast<float *>(static_cast<char *>(workspace) + round16(w.bytes));
+    float *zt_t = reinterpret_cast<float *>(reinterpret_cast<char *>(st_t) + round16((size_t)E * N * G * sizeof(float)));
+    void *zero_out = (tpe != nullptr) ? out : nullptr;
+    int rc;
+    if (L == 1) rc = launch_act_quant<1>(x, FQL_DTYPE_F32, nullptr, 0, w, T, K, Kp, MBT, zero_out, FQL_DTYPE_F32, N, tpe, offs, E, st);
+    else if (L == 2) rc = launch_act_quant<2>(x, FQL_DTYPE_F32, nullptr, 0, w, T, K, Kp, MBT, zero_out, FQL_DTYPE_F32, N, tpe, offs, E, st);
+    else rc = launch_act_quant<3>(x, FQL_DTYPE_F32, nullptr, 0, w, T, K, Kp, MBT, zero_out, FQL_DTYPE_F32, N, tpe, offs, E, st);
+    if (rc != FQL_OK) return rc;
+    (void)hipGetLastError();
+    const size_t total = (size_t)E * N * G;
+    hipLaunchKernelGGL(transpose_ng_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, scales, zps, st_t, zt_t, N, G, total);
+    if (hipGetLastError() != hipSuccess) return FQL_ERR_LAUNCH;
+    const dim3 grid((N + 127) / 128, (T + FQL_MB - 1) / FQL_MB, E);
+    if (L == 1) hipLaunchKernelGGL(group_i8_kernel<1>, grid, dim3(256), 0, st, w.limbs, w.delta, packed, st_t, zt_t, out, tpe, offs, E, T, K, MBT, N, group, bias);
+    else if (L == 2) hipLaunchKernelGGL(group_i8_kernel<2>, grid, dim3(256), 0, st, w.limbs, w.delta, packed, st_t, zt_t, out, tpe, offs, E, T, K, MBT, N, group, bias);
+    else hipLaunchKernelGGL(group_i8_kernel<3>, grid, dim3(256), 0, st, w.limbs, w.delta, packed, st_t, zt_t, out, tpe, offs, E, T, K, MBT, N, group, bias);
+    return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
+}
+
+int fql_linear_group_ws_fwd_f32(const float *x, const uint8_t *packed, const float *scales, const float *zps,
+                                const float *bias, float *out, int B, int K, int N, int group_size, int precision,
+                                void *workspace, size_t workspace_bytes, void *stream)
+{
+    return group_ws_entry(x, packed, scales, zps, bias, out, nullptr, nullptr, 1, B, K, N, group_size, precision, workspace,
+                          workspace_bytes, stream);
+}
+
+int fql_moe_group_ws_fwd_f32(const uint8_t *packed, const float *scales, const float *zps, const float *inputs,
+                             const int32_t *tokens_per_expert, const int32_t *input_offsets, float *out, int E, int T,
+                             int K, int N, int group_size, int precision, void *workspace, size_t workspace_bytes,
+                             void *stream)
+{
+    if (!tokens_per_expert || !input_offsets) return FQL_ERR_NULL_POINTER;
+    return group_ws_entry(inputs, packed, scales, zps, nullptr, out, tokens_per_expert, input_offsets, E, T, K, N, group_size,
+                          precision, workspace, workspace_bytes, stream);
+}
+
 int fql_linear_group_fwd_f32(const float *x, const uint8_t *packed, const float *scales, const float *zps,
                              const float *bias, float *out, int B, int K, int N, int group_size, void *stream)
 {
@@ -1042,6 +1114,7 @@ FQL_API int fql_debug_trace(unsigned long long *dst)
 FQL_API int fql_tune_set_act_single_rows(int rows) { const int old = g_act_single_rows; if (rows >= 0) g_act_single_rows = rows; return old; }
 FQL_API int fql_tune_set_balance_tiles(int on) { const int old = g_balance_tiles; g_balance_tiles = on ? 1 : 0; return old; }
 FQL_API int fql_tune_set_group_mfma(int on) { const int old = g_group_mfma; g_group_mfma = on ? 1 : 0; return old; }
+FQL_API int fql_tune_set_group_i8(int on) { const int old = g_group_i8; g_group_i8 = on ? 1 : 0; return old; }
 FQL_API int fql_tune_set_gemv_max_rows(int rows) { const int old = g_gemv_max_rows; if (rows >= 0 && rows <= 4) g_gemv_max_rows = rows; return old; }
 FQL_API int fql_tune_num_configs(void) { return FQL_NUM_CFG; }
 FQL_API int fql_tune_num_rows32_configs(void) { return FQL_NUM_ROWS32; }

@@ -76,7 +76,7 @@ def linear_forward(input, packed_weights, scales, zero_points, precision="defaul
     if packed_dim != K // 2 or K % 2 != 0:
         raise RuntimeError("packed_weights dim 1 must be input_dim / 2")
     if scales.dim() == 2 and scales.shape[1] > 1:           # per-group scales along K (float32 contraction: include/fql_int4.h)
-        out = _linear_group_forward(input, packed_weights, scales, zero_points, bias)
+        out = _linear_group_forward(input, packed_weights, scales, zero_points, bias, precision)
         return out.squeeze(0) if squeeze else out
     # not checked by the reference (silent UB there); checked here
     if scales.numel() != N or zero_points.numel() != N:
@@ -108,7 +108,7 @@ def linear_forward(input, packed_weights, scales, zero_points, precision="defaul
     return out.squeeze(0) if squeeze else out                      # :373-375
 
 
-def _linear_group_forward(input, packed_weights, scales, zero_points, bias):
+def _linear_group_forward(input, packed_weights, scales, zero_points, bias, precision="default"):
     """Per-group scales along K (``scales`` / ``zero_points`` [N, K / group_size]): fql_linear_group_fwd_f32."""
     B, K = input.shape
     N = packed_weights.shape[0]
@@ -126,16 +126,19 @@ def _linear_group_forward(input, packed_weights, scales, zero_points, bias):
             raise RuntimeError("bias must be a float32 tensor with output_dim elements on the input's device")
         bias = bias.contiguous()
     out = torch.empty((B, N), dtype=torch.float32, device=dev)
+    prec = _precision(precision)
     with torch.cuda.device(dev):
-        rc = _native.lib().fql_linear_group_fwd_f32(input.data_ptr(), packed_weights.data_ptr(), scales.contiguous().data_ptr(),
-                                                    zero_points.contiguous().data_ptr(),
-                                                    None if bias is None else bias.data_ptr(), out.data_ptr(), B, K, N,
-                                                    group, _stream_ptr(dev))
-    _native.check(rc, "fql_linear_group_fwd_f32")
+        L = _native.lib()
+        ws, ws_ptr = _workspace(L.fql_group_workspace_bytes(1, B, K, N, group, prec), dev)
+        rc = L.fql_linear_group_ws_fwd_f32(input.data_ptr(), packed_weights.data_ptr(), scales.contiguous().data_ptr(),
+                                           zero_points.contiguous().data_ptr(),
+                                           None if bias is None else bias.data_ptr(), out.data_ptr(), B, K, N,
+                                           group, prec, ws_ptr, 0 if ws is None else ws.numel(), _stream_ptr(dev))
+    _native.check(rc, "fql_linear_group_ws_fwd_f32")
     return out
 
 
-def moe_group_forward(packed_weights, scales, zero_points, inputs, tokens_per_expert, input_offsets):
+def moe_group_forward(packed_weights, scales, zero_points, inputs, tokens_per_expert, input_offsets, precision="default"):
     """Grouped per-expert INT4 GEMM with per-GROUP scales along K: ``scales`` / ``zero_points`` [E, N, K / group_size].
     Float32 contraction (include/fql_int4.h); rows no expert covers are zero."""
     if not inputs.is_cuda or inputs.dtype != torch.float32 or inputs.dim() != 2 or packed_weights.dim() != 3:
@@ -150,12 +153,15 @@ def moe_group_forward(packed_weights, scales, zero_points, inputs, tokens_per_ex
     tpe = tokens_per_expert.to(device=dev, dtype=torch.int32).contiguous()
     offs = input_offsets.to(device=dev, dtype=torch.int32).contiguous()
     out = torch.empty((T, N), dtype=torch.float32, device=dev)
+    prec = _precision(precision)
     with torch.cuda.device(dev):
-        rc = _native.lib().fql_moe_group_fwd_f32(packed_weights.contiguous().data_ptr(), scales.contiguous().data_ptr(),
-                                                 zero_points.contiguous().data_ptr(), inputs.contiguous().data_ptr(),
-                                                 tpe.data_ptr(), offs.data_ptr(), out.data_ptr(), E, T, K, N, group,
-                                                 _stream_ptr(dev))
-    _native.check(rc, "fql_moe_group_fwd_f32")
+        L = _native.lib()
+        ws, ws_ptr = _workspace(L.fql_group_workspace_bytes(E, T, K, N, group, prec), dev)
+        rc = L.fql_moe_group_ws_fwd_f32(packed_weights.contiguous().data_ptr(), scales.contiguous().data_ptr(),
+                                        zero_points.contiguous().data_ptr(), inputs.contiguous().data_ptr(),
+                                        tpe.data_ptr(), offs.data_ptr(), out.data_ptr(), E, T, K, N, group, prec,
+                                        ws_ptr, 0 if ws is None else ws.numel(), _stream_ptr(dev))
+    _native.check(rc, "fql_moe_group_ws_fwd_f32")
     return out
 
 

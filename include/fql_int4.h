@@ -194,6 +194,24 @@ FQL_API int fql_moe_group_fwd_f32(const uint8_t *packed, const float *scales, co
                                   const int32_t *input_offsets, float *out, int E, int T, int K, int N,
                                   int group_size, void *stream);
 
+/* The same two calls WITH a workspace (fql_group_workspace_bytes bytes, 16-byte aligned): batches of 48 or more rows per
+ * group with K % 256 == 0 and group_size % 64 == 0 then run on the INT8 matrix cores -- the activation limbs of the
+ * per-row path (`precision` as there: exact / fast / int8), integer dot products and limb sums per group, folded in
+ * float32 with the group's scale and zero point at the end of every group (csrc/fql_group_i8.h); 2.5-3x the per-row
+ * path's time instead of 6x.  The residual limb set of heavy-tailed rows is not visited on this path.  Every other shape, or a NULL / short workspace, takes the float32 paths above. */
+FQL_API size_t fql_group_workspace_bytes(int E, int T, int K, int N, int group_size, int precision);
+
+FQL_API int fql_linear_group_ws_fwd_f32(const float *x, const uint8_t *packed, const float *scales,
+                                        const float *zps, const float *bias, float *out, int B, int K, int N,
+                                        int group_size, int precision, void *workspace, size_t workspace_bytes,
+                                        void *stream);
+
+FQL_API int fql_moe_group_ws_fwd_f32(const uint8_t *packed, const float *scales, const float *zps,
+                                     const float *inputs, const int32_t *tokens_per_expert,
+                                     const int32_t *input_offsets, float *out, int E, int T, int K, int N,
+                                     int group_size, int precision, void *workspace, size_t workspace_bytes,
+                                     void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Format helpers on the device (same unpack code path as the GEMM kernels; bit-exact).
  *   fql_unpack_u8     : q[i][2j] = packed[i][j] & 15, q[i][2j+1] = packed[i][j] >> 4

@@ -763,7 +763,36 @@ def test_per_group_scales_linear(fq, B, N, K, group):
     assert torch.allclose(m(xt.cuda()).cpu(), m.cpu()(xt), atol=1e-3, rtol=1e-5)
 
 
-@pytest.mark.parametrize("E,N,K,group,counts", [(4, 96, 256, 64, [9, 0, 17, 5]), (4, 136, 512, 128, [150, 0, 40, 3]),
+@pytest.mark.parametrize("B,N,K,group", [(64, 256, 1024, 128), (512, 384, 4096, 128), (50, 100, 512, 64), (49, 72, 512, 256)])
+@pytest.mark.parametrize("prec,tol", [("exact", EXACT_REL_FRO), ("fast", FAST_REL_FRO), ("int8", INT8_REL_FRO)])
+def test_per_group_scales_integer_matrix_cores(fq, B, N, K, group, prec, tol):
+    """Batches of >= 48 rows with K % 256 == 0 and group % 64 == 0: the per-group path on the INT8 matrix cores
+    (csrc/fql_group_i8.h: per-group integer dot products and limb sums, folded in float32 at the end of every group),
+    against the float64 per-group dequantize-then-matmul, at the tolerances of the per-row modes; and the float32
+    matrix-core path (the same call with the integer kernel switched off) agrees with it to float32 noise."""
+    from fused_int4_amd import ops, _native
+    lib = _native.lib()
+    rng = np.random.default_rng(B + K + group)
+    w = rng.standard_normal((N, K)).astype(np.float32)
+    p, s, z = O.quantize_weights_grouped(w, group)
+    x = rng.standard_normal((B, K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = O.reference_linear_grouped(x, p, s, z)
+    got = ops.linear_forward(dev(x), dev(p), dev(s), dev(z), precision=prec).cpu().numpy()
+    assert rel_fro(got, ref) < tol, rel_fro(got, ref)
+    gotb = ops.linear_forward(dev(x), dev(p), dev(s), dev(z), precision=prec, bias=dev(bias)).cpu().numpy()
+    assert np.array_equal(gotb, got + bias[None, :])
+    if prec == "exact":
+        try:
+            assert lib.fql_tune_set_group_i8(0) == 1
+            f32 = ops.linear_forward(dev(x), dev(p), dev(s), dev(z)).cpu().numpy()
+        finally:
+            lib.fql_tune_set_group_i8(1)
+        assert rel_fro(f32, ref) < FMA_REL_FRO
+        assert rel_fro(got, f32) < 3e-6 and not np.array_equal(got, f32)      # two different kernels did run
+
+
+@pytest.mark.parametrize("E,N,K,group,counts", [(4, 96, 256, 64, [9, 0, 17, 5]), (4, 136, 512, 128, [150, 0, 40, 3]), (3, 136, 512, 128, [150, 70, 30]),
                                                 (3, 70, 192, 32, [260, 1, 66])])
 def test_per_group_scales_grouped_moe(fq, E, N, K, group, counts):
     from fused_int4_amd import ops
