@@ -23,6 +23,8 @@ namespace {
 // B = 2 / 3 / 4 and 16.2-16.5 us at B = 5..16: profiles/r02_linear_batch_sweep.txt).  Tuning hook below.
 int g_gemv_max_rows = 2;
 int g_group_i8 = 1;                    // per-group scales: the INT8 matrix-core kernel where eligible (A/B hook below)
+int g_group_i8_min_rows = 40;          // ... from this many rows on for one matrix (below: the float32 matrix-core kernel; measured
+int g_group_i8_min_rows_grouped = 8;   //     crossover 32..48), and from 8 rows per expert on for grouped calls (190 vs 230 us at 8 x 8 rows)
 int g_group_mfma = 1;                  // per-group scales: the float32 matrix-core kernel for batches (A/B hook below)
 int g_act_single_rows = 512;          // pre-pass: one row per workgroup up to this many padded rows (tuning hook below)
 
@@ -817,7 +819,7 @@ static int group_entry(const float *x, const uint8_t *packed, const float *scale
 static bool group_i8_eligible(int L, int E, int T, int K, int N, int group, const void *x, const void *packed, bool grouped)
 {
     const int groups = grouped ? E : 1;
-    return g_group_i8 && L >= 1 && L <= 3 && K % FQL_KB == 0 && group % 64 == 0 && K % group == 0 && (T + groups - 1) / groups >= 48 &&
+    return g_group_i8 && L >= 1 && L <= 3 && K % FQL_KB == 0 && group % 64 == 0 && K % group == 0 && (T + groups - 1) / groups >= (grouped ? g_group_i8_min_rows_grouped : g_group_i8_min_rows) &&
            aligned16(packed) && (reinterpret_cast<uintptr_t>(x) % 4 == 0) && N >= 4 && (T + FQL_MB - 1) / FQL_MB + 1 <= 65535 && E <= 65535;
 }
 
@@ -1114,6 +1116,7 @@ FQL_API int fql_debug_trace(unsigned long long *dst)
 FQL_API int fql_tune_set_act_single_rows(int rows) { const int old = g_act_single_rows; if (rows >= 0) g_act_single_rows = rows; return old; }
 FQL_API int fql_tune_set_balance_tiles(int on) { const int old = g_balance_tiles; g_balance_tiles = on ? 1 : 0; return old; }
 FQL_API int fql_tune_set_group_mfma(int on) { const int old = g_group_mfma; g_group_mfma = on ? 1 : 0; return old; }
+FQL_API int fql_tune_set_group_i8_min_rows(int rows) { const int old = g_group_i8_min_rows; if (rows >= 1) { g_group_i8_min_rows = rows; g_group_i8_min_rows_grouped = rows; } return old; }
 FQL_API int fql_tune_set_group_i8(int on) { const int old = g_group_i8; g_group_i8 = on ? 1 : 0; return old; }
 FQL_API int fql_tune_set_gemv_max_rows(int rows) { const int old = g_gemv_max_rows; if (rows >= 0 && rows <= 4) g_gemv_max_rows = rows; return old; }
 FQL_API int fql_tune_num_configs(void) { return FQL_NUM_CFG; }

@@ -194,8 +194,8 @@ FQL_API int fql_moe_group_fwd_f32(const uint8_t *packed, const float *scales, co
                                   const int32_t *input_offsets, float *out, int E, int T, int K, int N,
                                   int group_size, void *stream);
 
-/* The same two calls WITH a workspace (fql_group_workspace_bytes bytes, 16-byte aligned): batches of 48 or more rows per
- * group with K % 256 == 0 and group_size % 64 == 0 then run on the INT8 matrix cores -- the activation limbs of the
+/* The same two calls WITH a workspace (fql_group_workspace_bytes bytes, 16-byte aligned): batches (40 or more rows of one
+ * matrix, 8 or more rows per expert) with K % 256 == 0 and group_size % 64 == 0 then run on the INT8 matrix cores -- the activation limbs of the
  * per-row path (`precision` as there: exact / fast / int8), integer dot products and limb sums per group, folded in
  * float32 with the group's scale and zero point at the end of every group (csrc/fql_group_i8.h); 2.5-3x the per-row
  * path's time instead of 6x.  The residual limb set of heavy-tailed rows is not visited on this path.  Every other shape, or a NULL / short workspace, takes the float32 paths above. */

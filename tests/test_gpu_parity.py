@@ -766,7 +766,7 @@ def test_per_group_scales_linear(fq, B, N, K, group):
 @pytest.mark.parametrize("B,N,K,group", [(64, 256, 1024, 128), (512, 384, 4096, 128), (50, 100, 512, 64), (49, 72, 512, 256)])
 @pytest.mark.parametrize("prec,tol", [("exact", EXACT_REL_FRO), ("fast", FAST_REL_FRO), ("int8", INT8_REL_FRO)])
 def test_per_group_scales_integer_matrix_cores(fq, B, N, K, group, prec, tol):
-    """Batches of >= 48 rows with K % 256 == 0 and group % 64 == 0: the per-group path on the INT8 matrix cores
+    """Batches (>= 40 rows of one matrix, >= 8 rows per expert) with K % 256 == 0 and group % 64 == 0: the per-group path on the INT8 matrix cores
     (csrc/fql_group_i8.h: per-group integer dot products and limb sums, folded in float32 at the end of every group),
     against the float64 per-group dequantize-then-matmul, at the tolerances of the per-row modes; and the float32
     matrix-core path (the same call with the integer kernel switched off) agrees with it to float32 noise."""

@@ -8,6 +8,9 @@ import fused_int4_amd as fq
 from fused_int4_amd import ops
 
 dev = torch.device("cuda:0")
+if len(sys.argv) > 1:
+    from fused_int4_amd import _native
+    print("group i8 min rows", _native.lib().fql_tune_set_group_i8_min_rows(int(sys.argv[1])), "->", sys.argv[1])
 K, N, G = 4096, 11008, 128
 g = torch.Generator(device=dev).manual_seed(0)
 NSETS = 36
@@ -37,7 +40,7 @@ for i in range(NSETS):
     row_sets.append(fq.quantize_weights(w))
     grp_sets.append(fq.quantize_weights(w, group_size=G))
 bias = torch.randn(N, device=dev, generator=g)
-for B in (1, 16, 64, 128, 256, 512):
+for B in (8, 16, 32, 48, 64, 512):
     x = torch.randn(B, K, device=dev, generator=g)
     t_row = timed(lambda s: ops.linear_forward(x, *s), row_sets)
     t_bias = timed(lambda s: ops.linear_forward(x, *s, bias=bias), row_sets)
@@ -55,7 +58,7 @@ for i in range(4):
         p, s, z = fq.quantize_weights(w, group_size=G); Pg.append(p); Sg.append(s); Zg.append(z)
     moe_row.append((torch.stack(P), torch.stack(S), torch.stack(Z)))
     moe_grp.append((torch.stack(Pg), torch.stack(Sg), torch.stack(Zg)))
-for m in (8, 128):
+for m in (8, 16, 32, 128):
     T = E * m
     x = torch.randn(T, K, device=dev, generator=g)
     tpe = torch.full((E,), m, dtype=torch.int32, device=dev)
