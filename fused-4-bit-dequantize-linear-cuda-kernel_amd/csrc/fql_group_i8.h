@@ -15,7 +15,6 @@
 // 2 v + (lane >> 5) of the row's 128-byte stage segment for step 2 v + b, the pairing the pre-pass's layout assumes --
 // unpacked in registers.  Steps 2 v and 2 v + 1 together cover k = 64 v .. 64 v + 63 of a stage, so groups are multiples
 // of 64.  Scales / zero points are read from a [E][G][N] transpose (one small kernel per call) as 16-byte loads.
-// Heavy-tailed rows: the residual limb set is not visited here (those rows keep the 8L-1 bits of the main set).
 #pragma once
 #include "fql_common.h"
 
@@ -39,7 +38,7 @@ __global__ __launch_bounds__(256) void group_i8_kernel(
     const int8_t *__restrict__ limbs, const float *__restrict__ delta, const uint8_t *__restrict__ packed,
     const float *__restrict__ scales_t, const float *__restrict__ zps_t, float *__restrict__ out,
     const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs, int E, int T, int K, int MBT, int N, int group,
-    const float *__restrict__ bias)
+    const float *__restrict__ bias, int has_res)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int e = blockIdx.z;
@@ -72,6 +71,18 @@ __global__ __launch_bounds__(256) void group_i8_kernel(
     const int8_t *abase = limbs + (size_t)mb * 8192 + lane * 16;
     const size_t a_stage = (size_t)MBT * 8192, a_limb = (size_t)KB * a_stage;
 
+    // Heavy-tailed rows (csrc/fql_act_quant.h pass 3): a row block that holds one is walked a second time over the
+    // residual limb set (limbs + L planes, quantum delta[T + t], 0 for rows without one) and the two results are added.
+    const int rl = rb * FQL_MB + l31;
+    const int t = row_lo + (rl < cnt ? rl : 0);
+    const float d_main = delta[t];
+    const float d_res = has_res ? delta[(size_t)T + t] : 0.0f;
+    const int nset = __builtin_amdgcn_readfirstlane((__ballot(rl < cnt && d_res != 0.0f) != 0ull) ? 2 : 1);
+    v16f res;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) res[r] = 0.0f;
+  for (int set = 0; set < nset; ++set) {
+    const int8_t *abase_s = abase + (size_t)set * L * a_limb;
     v16i acc[L];
     v16f f;
     int xs[L];
@@ -91,7 +102,7 @@ __global__ __launch_bounds__(256) void group_i8_kernel(
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int l = 0; l < L; ++l)
-                dst[b][l] = *reinterpret_cast<const v4i *>(abase + l * a_limb + kb * a_stage + (2 * v + b) * 1024);
+                dst[b][l] = *reinterpret_cast<const v4i *>(abase_s + l * a_limb + kb * a_stage + (2 * v + b) * 1024);
     };
     auto load_w = [&](int pair) -> uint4 {
         const int kb = pair >> 2, v = pair & 3;
@@ -167,11 +178,13 @@ __global__ __launch_bounds__(256) void group_i8_kernel(
             }
         }
     }
+    const float dset = set == 0 ? d_main : d_res;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) res[r] = (set == 0) ? f[r] * dset : res[r] + f[r] * dset;
+  }
     // ---- lane owns row t, registers 4 q .. 4 q + 3 are 4 consecutive columns
-    const int rl = rb * FQL_MB + l31;
     if (rl >= cnt) return;
-    const int t = row_lo + rl;
-    const float d = delta[t];
+    const int n_q = n_blk + 4 * g2;
     const bool vec = ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(256) void group_i8_kernel(
         float o[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            o[c] = f[4 * q + c] * d;
+            o[c] = res[4 * q + c];
             if (bias != nullptr && nq + c < N) o[c] += bias[(size_t)e * N + nq + c];
         }
         store_out4(out, 0, (size_t)t * N, nq, N, vec, o);

@@ -860,9 +860,9 @@ static int group_ws_entry(const float *x, const uint8_t *packed, const float *sc
     hipLaunchKernelGGL(transpose_ng_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, scales, zps, st_t, zt_t, N, G, total);
     if (hipGetLastError() != hipSuccess) return FQL_ERR_LAUNCH;
     const dim3 grid((N + 127) / 128, (T + FQL_MB - 1) / FQL_MB, E);
-    if (L == 1) hipLaunchKernelGGL(group_i8_kernel<1>, grid, dim3(256), 0, st, w.limbs, w.delta, packed, st_t, zt_t, out, tpe, offs, E, T, K, MBT, N, group, bias);
-    else if (L == 2) hipLaunchKernelGGL(group_i8_kernel<2>, grid, dim3(256), 0, st, w.limbs, w.delta, packed, st_t, zt_t, out, tpe, offs, E, T, K, MBT, N, group, bias);
-    else hipLaunchKernelGGL(group_i8_kernel<3>, grid, dim3(256), 0, st, w.limbs, w.delta, packed, st_t, zt_t, out, tpe, offs, E, T, K, MBT, N, group, bias);
+    if (L == 1) hipLaunchKernelGGL(group_i8_kernel<1>, grid, dim3(256), 0, st, w.limbs, w.delta, packed, st_t, zt_t, out, tpe, offs, E, T, K, MBT, N, group, bias, has_residual(L, false) ? 1 : 0);
+    else if (L == 2) hipLaunchKernelGGL(group_i8_kernel<2>, grid, dim3(256), 0, st, w.limbs, w.delta, packed, st_t, zt_t, out, tpe, offs, E, T, K, MBT, N, group, bias, has_residual(L, false) ? 1 : 0);
+    else hipLaunchKernelGGL(group_i8_kernel<3>, grid, dim3(256), 0, st, w.limbs, w.delta, packed, st_t, zt_t, out, tpe, offs, E, T, K, MBT, N, group, bias, has_residual(L, false) ? 1 : 0);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 

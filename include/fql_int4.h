@@ -198,7 +198,7 @@ FQL_API int fql_moe_group_fwd_f32(const uint8_t *packed, const float *scales, co
  * matrix, 8 or more rows per expert) with K % 256 == 0 and group_size % 64 == 0 then run on the INT8 matrix cores -- the activation limbs of the
  * per-row path (`precision` as there: exact / fast / int8), integer dot products and limb sums per group, folded in
  * float32 with the group's scale and zero point at the end of every group (csrc/fql_group_i8.h); 2.5-3x the per-row
- * path's time instead of 6x.  The residual limb set of heavy-tailed rows is not visited on this path.  Every other shape, or a NULL / short workspace, takes the float32 paths above. */
+ * path's time instead of 6x.  Every other shape, or a NULL / short workspace, takes the float32 paths above. */
 FQL_API size_t fql_group_workspace_bytes(int E, int T, int K, int N, int group_size, int precision);
 
 FQL_API int fql_linear_group_ws_fwd_f32(const float *x, const uint8_t *packed, const float *scales,

@@ -190,3 +190,20 @@ def test_heavy_tails_every_tile_configuration(fq, prec):
     # 16-bit outputs: rounded once, from the float32 sum of main and residual parts
     o16 = ops.moe_forward_any(dP, dS, dZ, dx, None, dc, do, precision=prec, out_dtype=torch.bfloat16)
     assert torch.equal(o16.cpu(), torch.from_numpy(prod).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("prec,tol", [("exact", EXACT_REL_FRO), ("fast", 3e-4)])
+def test_per_group_heavy_tails(fq, prec, tol):
+    """Per-group scales on the INT8 matrix cores (csrc/fql_group_i8.h) walk the residual limb set of flagged rows as the
+    per-row kernels do: outlier channels stay inside the mode's constant, row by row."""
+    from fused_int4_amd import ops
+    rng = np.random.default_rng(123)
+    Kg, Ng, Bg, group = 1024, 200, 96, 128
+    w = rng.standard_normal((Ng, Kg)).astype(np.float32)
+    p, s, z = O.quantize_weights_grouped(w, group)
+    x = rng.standard_normal((Bg, Kg)).astype(np.float32)
+    x[::3, [7, 500]] *= 700.0                                  # every third row heavy-tailed, the others clean
+    out = ops.linear_forward(dev(x), dev(p), dev(s), dev(z), precision=prec).cpu().numpy()
+    ref = O.reference_linear_grouped(x, p, s, z)
+    for t in range(Bg):
+        assert rel_fro(out[t], ref[t]) < tol, (t, rel_fro(out[t], ref[t]))
