@@ -57,6 +57,27 @@ for case in range(n_cases):
         d = lambda a: torch.from_numpy(a).cuda()
         out = ops.linear_forward(d(x), d(p), d(s), d(z), precision=prec).cpu().numpy()
         key = f"linear/{prec}"
+    if case % 8 == 5:                      # per-group scales along K: every dispatch branch of that path
+        group = int(rng.choice([16, 32, 64, 128, 256]))
+        Kg = int(rng.choice([256, 512, 768, 192, 64, 1024]))
+        if Kg % group != 0:
+            group = 64 if Kg % 64 == 0 else 32
+        if group >= Kg:                    # (one group per row IS the per-row layout: not this path)
+            group = Kg // 2
+        Ng = int(rng.choice([5, 64, 130, 264]))
+        Bg = int(rng.choice([1, 2, 3, 4, 9, 39, 40, 41, 100, 300]))
+        wq = O.quantize_weights_grouped(rng.standard_normal((Ng, Kg)).astype(np.float32), group)
+        xg = rng.standard_normal((Bg, Kg)).astype(np.float32)
+        refg = O.reference_linear_grouped(xg, *wq)
+        d = lambda a: torch.from_numpy(a).cuda()
+        outg = ops.linear_forward(d(xg), d(wq[0]), d(wq[1]), d(wq[2]), precision=prec).cpu().numpy()
+        int_path = Bg >= 40 and Kg % 256 == 0 and group % 64 == 0 and Ng >= 4
+        tolg = TOL[prec] if int_path else 2e-6
+        if int_path and prec == "int8" and outg.size < 2000:
+            tolg = 6e-2
+        rg = rel(outg, refg)
+        worst[f"group/{prec if int_path else 'f32'}"] = max(worst.get(f"group/{prec if int_path else 'f32'}", 0.0), rg)
+        assert rg < tolg, ("per-group", case, rg, Bg, Ng, Kg, group, prec)
     mfma = (K % 32 == 0) and (grouped or x.shape[0] > 2)
     tol = TOL[prec] if mfma else 2e-6
     if mfma and prec == "int8" and out.size < 2000:
