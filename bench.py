@@ -459,13 +459,23 @@ def main():
                 traffic = tj.get("hbm_bytes_per_launch") if same else None     # PMC figure of THIS shape only
             except Exception:
                 traffic = None
+        kname = "gemm_i8_kernel"
+        try:    # the kernel family the library picks for this shape (tuning hook; ids as in fql_tune_gemm_i8_f32)
+            from fused_int4_amd import _native
+            cfg_id = _native.lib().fql_tune_chosen_cfg(ops._precision(prec), a.experts if a.workload == "moe" else 1, rows, K, N,
+                                                       1 if a.workload == "moe" else 0)
+            kname = ("gemm_w4_kernel" if cfg_id >= 300 else "gemm_i8_rows16_kernel" if cfg_id >= 200 else
+                     "gemm_i8_rows32_kernel" if cfg_id >= 100 else "gemm_i8_kernel")
+            extra["gemm_tile_configuration"] = cfg_id
+        except Exception:
+            pass
         if mfma_floor_ms >= hbm_floor_ms:
-            roofline = {"bound": "mfma", "kernel": "gemm_i8_kernel", "achieved": mfma_achieved, "peak": MFMA_I8_PEAK_TOPS,
+            roofline = {"bound": "mfma", "kernel": kname, "achieved": mfma_achieved, "peak": MFMA_I8_PEAK_TOPS,
                         "unit": "TFLOP/s", "frac": mfma_achieved / MFMA_I8_PEAK_TOPS, "traffic": traffic,
                         "note": f"algorithmic flops 2*rows*K*N counted once; the kernel issues {limbs} INT8 MFMA passes "
                                 f"(one per activation limb), so frac <= 1/{limbs} by construction"}
         else:
-            roofline = {"bound": "hbm", "kernel": "gemm_i8_kernel", "achieved": hbm_achieved, "peak": HBM_PEAK_GBPS,
+            roofline = {"bound": "hbm", "kernel": kname, "achieved": hbm_achieved, "peak": HBM_PEAK_GBPS,
                         "unit": "GB/s", "frac": hbm_achieved / HBM_PEAK_GBPS, "traffic": traffic}
         extra["roofline_hbm_packed_weights"] = {"achieved": hbm_achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                                 "frac": hbm_achieved / HBM_PEAK_GBPS, "bytes": weight_bytes}

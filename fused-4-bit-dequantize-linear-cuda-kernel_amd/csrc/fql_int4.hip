@@ -15,6 +15,7 @@
 #include "fql_generic.h"
 #include "fql_quantize.h"
 #include "fql_routing.h"
+#include "fql_w4_launch.h"
 
 namespace {
 
@@ -26,6 +27,7 @@ int g_group_i8 = 1;                    // per-group scales: the INT8 matrix-core
 int g_group_i8_min_rows = 40;          // ... from this many rows on for one matrix (below: the float32 matrix-core kernel; measured
 int g_group_i8_min_rows_grouped = 8;   //     crossover 32..48), and from 8 rows per expert on for grouped calls (190 vs 230 us at 8 x 8 rows)
 int g_group_mfma = 1;                  // per-group scales: the float32 matrix-core kernel for batches (A/B hook below)
+int g_use_w4 = 1;                      // 3 limbs, > 64 rows per group: the one-wave-per-SIMD kernel (fql_gemm_w4.h) instead of the 8-wave 128 x 192 one (A/B hook below)
 int g_act_single_rows = 512;          // pre-pass: one row per workgroup up to this many padded rows (tuning hook below)
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -172,7 +174,13 @@ constexpr int FQL_NUM_ROWS16 = 9;
     S4(2, 4, 2, 1)             /* 16 x 128, K split 2 ways */ \
     S4(3, 8, 4, 1)             /* 16 x 128, 8 fragments per wave */
 constexpr int FQL_NUM_ROWS16_W4 = 4;
-inline bool valid_cfg(int cfg) { return (cfg >= 0 && cfg < FQL_NUM_CFG) || (cfg >= 100 && cfg < 100 + FQL_NUM_ROWS32) ||
+// One wave per SIMD (fql_gemm_w4.h, its own translation unit): 128 x 192 tiles, 4 waves of 32 x 192.  ids 300 + i:
+// W(i, limbs, fragments per wave, activation ring depth in k-steps)
+#define FQL_W4_LIST(W)                                                                                             \
+    W(0, 3, 6, 8)              /* 3 limbs, full-stage activation ring */ \
+    W(1, 3, 6, 4)              /* 3 limbs, 4-step ring */
+constexpr int FQL_NUM_W4 = 2;
+inline bool valid_cfg(int cfg) { return (cfg >= 300 && cfg < 300 + FQL_NUM_W4) || (cfg >= 0 && cfg < FQL_NUM_CFG) || (cfg >= 100 && cfg < 100 + FQL_NUM_ROWS32) ||
            (cfg >= 200 && cfg < 200 + FQL_NUM_ROWS16) || (cfg >= 220 && cfg < 220 + FQL_NUM_ROWS16_W4);
 }
 
@@ -354,12 +362,48 @@ int launch_rows16_cfg(const Workspace &w, const uint8_t *packed, const float *sc
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
+// The one-wave-per-SIMD kernel: same tiles and column split as the wide kernel's 128 x 192 configuration.
+int launch_w4_cfg(int L, int nf, int depth, const Workspace &w, const uint8_t *packed, const float *scales, const float *zps,
+                  void *out, int out_dtype, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT,
+                  int N, hipStream_t st)
+{
+    if (Kp < 2 * FQL_KB) return FQL_ERR_BAD_SHAPE;           // its pipeline runs two weight stages ahead
+    const int BM = 128, BN = fql_w4_bn(L, nf);
+    const int cus = compute_units();
+    const int m_slots = (tpe == nullptr) ? (T + BM - 1) / BM : T / BM + E;
+    const int groups = (tpe == nullptr) ? 1 : E;
+    const long long m_even = (long long)groups * (((T + groups - 1) / groups + BM - 1) / BM);
+    const int n_tiles = (N + BN - 1) / BN;
+    int n_alt = balanced_n_tiles(N, BN / 32, m_even, cus);
+    if (n_alt == n_tiles) n_alt = 0;
+    long long blocks = (long long)(n_alt > n_tiles ? n_alt : n_tiles) * m_slots;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return FQL_ERR_BAD_SHAPE;
+    if (blocks > cus) blocks = cus;
+    FqlW4Args a;
+    a.limbs = w.limbs; a.delta = w.delta; a.rowsum = w.rowsum;
+    a.packed = packed; a.scales = scales; a.zps = zps;
+    a.out = out; a.out_kind = out_dtype;
+    a.tpe = tpe; a.offs = offs;
+    a.E = E; a.T = T; a.K = K; a.Kp = Kp; a.MBT = MBT; a.N = N;
+    a.n_tiles = n_tiles; a.m_slots = m_slots; a.n_alt = n_alt;
+    a.scratch = w.scratch; a.bias = w.bias;
+    a.blocks = blocks; a.stream = st;
+    const int rc = fql_w4_launch(L, nf, depth, a);
+    return rc == 0 ? FQL_OK : (rc == -2 ? FQL_ERR_BAD_SHAPE : FQL_ERR_LAUNCH);
+}
+
 template <int L>
 int launch_gemm(int cfg, const Workspace &w, const uint8_t *packed, const float *scales, const float *zps,
                 void *out, int out_dtype, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT,
                 int N, hipStream_t st)
 {
     switch (cfg) {
+#define W(i, l, nf, d)                                                                                            \
+    case 300 + i:                                                                                                 \
+        if (L != l) return FQL_ERR_BAD_SHAPE;                                                                      \
+        return launch_w4_cfg(l, nf, d, w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, st);
+        FQL_W4_LIST(W)
+#undef W
 #define X(id, wm, wn, nf, d, bp)                                                                                  \
     case id:                                                                                                      \
         return launch_gemm_cfg<L, wm, wn, nf, d, bp>(w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, \
@@ -464,6 +508,9 @@ inline int choose_cfg(int L, int E, int T, int K, int N, bool grouped)
         const long long cost = rounds * (cands[i].bn + 24);  // +24: per-tile prologue / epilogue
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cands[i].cfg; }
     }
+    // the same 128 x 192 tiles at one wave per SIMD (measured: 124.7 vs 134.4 us at configs[2], 182.6 vs 204.4 us under
+    // skewed routing, profiles/r03_w4_vs_wide.txt); its pipeline runs two 256-k weight stages ahead
+    if (best == 0 && g_use_w4 && padded_k(K) >= 2 * FQL_KB) best = 301;
     return best;
 }
 
@@ -1122,6 +1169,15 @@ FQL_API int fql_tune_set_gemv_max_rows(int rows) { const int old = g_gemv_max_ro
 FQL_API int fql_tune_num_configs(void) { return FQL_NUM_CFG; }
 FQL_API int fql_tune_num_rows32_configs(void) { return FQL_NUM_ROWS32; }
 FQL_API int fql_tune_num_rows16_configs(void) { return FQL_NUM_ROWS16; }
+FQL_API int fql_tune_num_w4_configs(void) { return FQL_NUM_W4; }
+// which tile configuration the product path picks for a shape (ids as in fql_tune_gemm_i8_f32; bench.py labels its roofline with it)
+FQL_API int fql_tune_chosen_cfg(int precision, int E, int T, int K, int N, int grouped)
+{
+    const int L = limbs_of(precision);
+    if (L < 0) return -1;
+    return is_f8(precision) ? choose_cfg_f8(E, T, N, grouped != 0) : choose_cfg(L, E, T, K, N, grouped != 0);
+}
+FQL_API int fql_tune_set_w4(int on) { const int old = g_use_w4; g_use_w4 = on ? 1 : 0; return old; }
 
 
 }  // extern "C"

@@ -174,7 +174,8 @@ def test_heavy_tails_every_tile_configuration(fq, prec):
     assert 0 < int((delta[1] != 0).sum()) < T
     outs = {}
     for cfg in (list(range(lib.fql_tune_num_configs())) + list(range(100, 100 + lib.fql_tune_num_rows32_configs()))
-                + list(range(200, 200 + lib.fql_tune_num_rows16_configs()))):
+                + list(range(200, 200 + lib.fql_tune_num_rows16_configs()))
+                + (list(range(300, 300 + lib.fql_tune_num_w4_configs())) if prec == "exact" else [])):
         out = torch.full((T, Nn), float("nan"), dtype=torch.float32, device="cuda")
         rc = ops.tune_gemm_i8(cfg, limbs, delta, rowsum, dP, dS, dZ, dc, do, out, E, T, Kk, Nn, prec)
         assert rc == 0, (cfg, rc)

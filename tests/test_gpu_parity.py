@@ -377,7 +377,8 @@ def test_every_tile_configuration_is_bit_identical(fq, prec, tol):
     limbs, delta, rowsum = ops.act_quant(dx, precision=prec, tokens_per_expert=dc, input_offsets=do)
     outs = {}
     for cfg in (list(range(lib.fql_tune_num_configs())) + list(range(100, 100 + lib.fql_tune_num_rows32_configs()))
-                + list(range(200, 200 + lib.fql_tune_num_rows16_configs()))):
+                + list(range(200, 200 + lib.fql_tune_num_rows16_configs()))
+                + (list(range(300, 300 + lib.fql_tune_num_w4_configs())) if prec == "exact" else [])):
         out = torch.full((T, N), float("nan"), dtype=torch.float32, device="cuda")
         rc = ops.tune_gemm_i8(cfg, limbs, delta, rowsum, dP, dS, dZ, dc, do, out, E, T, K, N, prec)
         assert rc == 0, (cfg, rc)

@@ -1,0 +1,116 @@
+"""GPU tests of the one-wave-per-SIMD GEMM (csrc/fql_gemm_w4.h; tuning ids 300..): bit for bit the results of the
+8-wave wide kernel (tuning id 0) on the same limbs, and within the exact mode's constant of the float64 oracle.
+
+Replaces (reference): csrc/moe_int4_kernel.cu:17-136, csrc/quantized_linear_kernel.cu:90-279."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import EXACT_REL_FRO, rel_fro
+from oracle import oracle as O
+from oracle import c_oracle as C
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fq():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import fused_int4_amd as pkg
+    from fused_int4_amd import _native
+    _native.lib()
+    return pkg
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def w4_ids():
+    from fused_int4_amd import _native
+    return list(range(300, 300 + _native.lib().fql_tune_num_w4_configs()))
+
+
+def make_moe(E, N, K, counts, seed, heavy_every=0):
+    rng = np.random.default_rng(seed)
+    q = [O.quantize_weights((rng.standard_normal((N, K)) * 0.02).astype(np.float32)) for _ in range(E)]
+    P, S, Z = (np.stack([t[i] for t in q]) for i in range(3))
+    counts = np.asarray(counts, np.int32)
+    offs = (np.cumsum(counts) - counts).astype(np.int32)
+    T = int(counts.sum())
+    x = rng.standard_normal((T, K)).astype(np.float32)
+    if heavy_every:
+        for t in range(0, T, heavy_every):
+            x[t, rng.choice(K, 2, replace=False)] *= 800.0
+    return P, S, Z, x, counts, offs
+
+
+def run_cfgs(ops, cfgs, limbs, delta, rowsum, dP, dS, dZ, dc, do, E, T, K, N):
+    outs = {}
+    for cfg in cfgs:
+        out = torch.full((T, N), float("nan"), dtype=torch.float32, device="cuda")
+        rc = ops.tune_gemm_i8(cfg, limbs, delta, rowsum, dP, dS, dZ, dc, do, out, E, T, K, N, "exact")
+        assert rc == 0, (cfg, rc)
+        torch.cuda.synchronize()
+        outs[cfg] = out
+    return outs
+
+
+@pytest.mark.parametrize("E,N,K,counts,heavy", [
+    (8, 352, 512, [128] * 8, 0),                             # 11 fragments: one 6- and one 5-fragment tile; two weight stages (the minimum)
+    (5, 200, 768, [0, 7, 33, 70, 129], 0),                   # ragged groups, N % 32 != 0, 4- and 3-fragment tiles
+    (6, 1100, 1024, [128, 1, 96, 64, 130, 32], 0),           # row blocks without rows: waves computing on zeros
+    (5, 200, 768, [0, 7, 33, 70, 129], 5),                   # heavy-tailed rows: residual pass + main pass
+    (4, 2080, 1280, [200, 128, 56, 128], 7),                 # several tiles per workgroup with residual visits in between
+    (3, 384, 4128, [100, 128, 12], 0),                       # K % 256 != 0 (zero-padded last stage), 17 stages
+])
+def test_w4_bit_identical_to_wide_kernel(fq, E, N, K, counts, heavy):
+    from fused_int4_amd import ops
+    P, S, Z, x, cnt, offs = make_moe(E, N, K, counts, 1234 + N, heavy)
+    T = x.shape[0]
+    dP, dS, dZ, dx, dc, do = dev(P), dev(S), dev(Z), dev(x), dev(cnt), dev(offs)
+    limbs, delta, rowsum = ops.act_quant(dx, precision="exact", tokens_per_expert=dc, input_offsets=do)
+    if heavy:
+        assert 0 < int((delta[1] != 0).sum()) < T
+    outs = run_cfgs(ops, [0] + w4_ids(), limbs, delta, rowsum, dP, dS, dZ, dc, do, E, T, K, N)
+    ref = C.moe_grouped(P, S, Z, x, cnt, offs)
+    assert rel_fro(outs[0].cpu().numpy(), ref) < EXACT_REL_FRO
+    for cfg in w4_ids():
+        assert torch.equal(outs[cfg], outs[0]), f"configuration {cfg} differs from the wide kernel"
+
+
+def test_w4_linear_many_tiles_per_workgroup(fq):
+    """One matrix, 8192 rows x 12480 columns: 64 x 65 = 4160 tiles on at most 256 workgroups, so every workgroup walks
+    more than the 16 tiles its LDS table describes at a time (the refill path)."""
+    from fused_int4_amd import ops
+    rng = np.random.default_rng(5)
+    N, K, T = 12480, 512, 8192
+    p, s, z = O.quantize_weights((rng.standard_normal((N, K)) * 0.02).astype(np.float32))
+    x = rng.standard_normal((T, K)).astype(np.float32)
+    dP, dS, dZ, dx = dev(p), dev(s), dev(z), dev(x)
+    limbs, delta, rowsum = ops.act_quant(dx, precision="exact")
+    outs = run_cfgs(ops, [0] + w4_ids(), limbs, delta, rowsum, dP, dS, dZ, None, None, 1, T, K, N)
+    rows = [0, 127, 128, 4097, 8191]
+    ref = C.linear_f64acc(x[rows], p, s, z)
+    assert rel_fro(outs[0][rows].cpu().numpy(), ref) < EXACT_REL_FRO
+    for cfg in w4_ids():
+        assert torch.equal(outs[cfg], outs[0]), f"configuration {cfg} differs from the wide kernel"
+
+
+def test_w4_headline_shape_bit_identical(fq):
+    """BASELINE configs[2] at full size (8 experts, 4096 -> 11008, 1024 routed rows), balanced and skewed routing."""
+    from fused_int4_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    E, K, N = 8, 4096, 11008
+    q = [fq.quantize_weights(torch.randn(N, K, device="cuda", generator=g) * 0.02) for _ in range(E)]
+    dP, dS, dZ = (torch.stack([t[i] for t in q]) for i in range(3))
+    for counts in ([128] * 8, [485, 230, 140, 90, 45, 24, 6, 4]):
+        cnt = torch.tensor(counts, dtype=torch.int32, device="cuda")
+        offs = (torch.cumsum(cnt, 0) - cnt).to(torch.int32)
+        T = int(sum(counts))
+        x = torch.randn(T, K, device="cuda", generator=g)
+        limbs, delta, rowsum = ops.act_quant(x, precision="exact", tokens_per_expert=cnt, input_offsets=offs)
+        outs = run_cfgs(ops, [0] + w4_ids(), limbs, delta, rowsum, dP, dS, dZ, cnt, offs, E, T, K, N)
+        for cfg in w4_ids():
+            assert torch.equal(outs[cfg], outs[0]), f"configuration {cfg} differs from the wide kernel ({counts})"
