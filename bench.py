@@ -574,6 +574,41 @@ def main():
                                                "hbm_GBps_packed_weights_e2e": weight_bytes / (ms_1 * 1e-3) / 1e9,
                                                "note": "one expert per row (the MoEINT4 call as the reference's harness makes it); not the headline"}
 
+    # ------------------------------------------------------------------ side measurement: the reference's DEFAULT routing
+    # distribution ("skewed", benchmark/run_moe_benchmark.py:106; routing.py:26-93) on the same weights and step
+    if (a.workload == "moe" and world == 1 and a.routing == "balanced" and prec in ("default", "exact")
+            and not a.no_side_modes):
+        route_s = R.simulate_routing(a.tokens, E, a.top_k, "skewed", dev, 42)
+        xs, tpe_s, offs_s, _ = R.dispatch_grouped(x_tok, route_s.expert_indices, E)
+        xs = xs.contiguous()
+
+        def step_skew():
+            P, S, Z = sets[step_i[0] % len(sets)]
+            step_i[0] += 1
+            return ops.moe_forward(P, S, Z, xs, None, tpe_s, offs_s, precision=prec)
+        t_wake = time.perf_counter()
+        while time.perf_counter() - t_wake < 0.1:
+            for _ in range(8):
+                step_skew()
+            torch.cuda.synchronize()
+        ns = max(20, a.steps)
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        for _ in range(ns):
+            step_skew()
+        torch.cuda.synchronize()
+        ms_s = (time.perf_counter() - tf0) / ns * 1e3
+        out_s = step_skew()
+        torch.cuda.synchronize()
+        Ps, Ss, Zs = sets[(step_i[0] - 1) % len(sets)]
+        chk = check_outputs(out_s, xs, Ps, Ss, Zs, tpe_s, offs_s, prec)
+        extra["skewed_routing"] = {"ms_per_step": ms_s, "tokens_per_expert": tpe_s.tolist(), "steps": ns,
+                                   "value": flops / (ms_s * 1e-3) / 1e12, "unit": "TFLOP/s",
+                                   "max_rel_err": chk["max_rel_err"],
+                                   "note": "the reference's default 'skewed' routing on the same weights; ratio to the headline step in "
+                                           "'vs_headline_step' is filled in below; not the headline"}
+        del out_s
+
     # ------------------------------------------------------------------ output check of the timed call (A12 / VERDICT r1)
     # the same call once more, compared with the oracle on sampled rows of every group; a wrong result fails the run
     if world == 1 and os.environ.get("FQL_BENCH_SKIP_CHECK") != "1":
@@ -599,6 +634,8 @@ def main():
             p, s, z = sets[0]
             cpu = cpu_baseline_linear(p, s, z, x, K, N)
 
+    if "skewed_routing" in extra:
+        extra["skewed_routing"]["vs_headline_step"] = extra["skewed_routing"]["ms_per_step"] / ms_per_step
     if rank == 0:
         line = {
             "metric": "fused INT4 GEMM effective TFLOP/s (ms, HBM GB/s and roofline fractions alongside)",

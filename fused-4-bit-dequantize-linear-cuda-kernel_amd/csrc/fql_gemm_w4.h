@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
     const float *__restrict__ scales, const float *__restrict__ zps, void *__restrict__ out, int out_kind,
     const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
     int E, int T, int K, int Kp, int MBT, int N, int n_tiles_min, int m_slots, float *__restrict__ res_scratch,
-    const float *__restrict__ bias, int n_tiles_alt)
+    const float *__restrict__ bias, int n_tiles_alt, int part)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = W4Cfg<L, NF, DEPTH>;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
     };
     if (tpe != nullptr) {
         int cp = 0, ct = 0;
-        for (int base = 0; base < E; base += 64) (void)expert_chunk(tpe, offs, E, T, C::BM, base, lane, cp, ct);
+        for (int base = 0; base < E; base += 64) (void)expert_chunk(tpe, offs, E, T, C::BM, base, lane, cp, ct, part);
         const int m_tiles = __builtin_amdgcn_readfirstlane(ct < m_slots ? ct : m_slots);
         pick_tiles(m_tiles);
         n_real = m_tiles * n_tiles;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         } else {
             int cp = 0, ct = 0;
             for (int base = 0; base < E && !tp.ok; base += 64) {
-                const ExpertLane x = expert_chunk(tpe, offs, E, T, C::BM, base, lane, cp, ct);
+                const ExpertLane x = expert_chunk(tpe, offs, E, T, C::BM, base, lane, cp, ct, part);
                 const unsigned long long hit = __ballot(ms >= x.tile_excl && ms < x.tile_excl + x.tiles);
                 if (hit) {
                     const int src = __ffsll((long long)hit) - 1;
@@ -422,26 +422,26 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
                     asm volatile("" : "+v"(up[2 * i]), "+v"(up[2 * i + 1]));              // pin the unpack to this slot
                 };
                 static_assert(NF == 6 && L == 3 && NVF == 1, "the slot plan below is written for 6 fragments x 3 limbs, the last fragment in VGPRs");
-                mm(0, 0); frag(fc, 5); fence();
-                mm(0, 1); frag(fc, 4); fence();
-                mm(0, 2); refill(0); fence();
+                mm(0, 0); fence(); frag(fc, 5); fence();
+                mm(0, 1); fence(); frag(fc, 4); fence();
+                mm(0, 2); fence(); refill(0); fence();
                 if (ks == KS - 1) {
                     // every wave has parked the next stage (steps 0..NF-1) and holds the last fragments of this one
                     wait_lgkmcnt0();
                     __builtin_amdgcn_s_barrier();
                 }
-                mm(1, 0); frag(fp, 0); fence();
-                mm(1, 1); refill(1); fence();
-                mm(1, 2); refill(2); fence();
-                mm(2, 0); frag(fp, 1); fence();
-                mm(2, 1); unpack(0); fence();
-                mm(2, 2); unpack(1); fence();
-                mm(3, 0); frag(fp, 2); fence();
-                mm(3, 1); unpack(2); fence();
-                mm(3, 2); unpack(3); fence();
-                mm(4, 0); frag(fp, 3); fence();
-                mm(4, 1); if (park) *reinterpret_cast<v4i *>(nb + wA0 + ks * 8192) = v4i{(int)up[0], (int)up[1], (int)up[2], (int)up[3]}; fence();
-                mm(4, 2); if (park) *reinterpret_cast<v4i *>(nb + wA1 + ks * 8192) = v4i{(int)up[4], (int)up[5], (int)up[6], (int)up[7]}; fence();
+                mm(1, 0); fence(); frag(fp, 0); fence();
+                mm(1, 1); fence(); refill(1); fence();
+                mm(1, 2); fence(); refill(2); fence();
+                mm(2, 0); fence(); frag(fp, 1); fence();
+                mm(2, 1); fence(); unpack(0); fence();
+                mm(2, 2); fence(); unpack(1); fence();
+                mm(3, 0); fence(); frag(fp, 2); fence();
+                mm(3, 1); fence(); unpack(2); fence();
+                mm(3, 2); fence(); unpack(3); fence();
+                mm(4, 0); fence(); frag(fp, 3); fence();
+                mm(4, 1); fence(); if (park) *reinterpret_cast<v4i *>(nb + wA0 + ks * 8192) = v4i{(int)up[0], (int)up[1], (int)up[2], (int)up[3]}; fence();
+                mm(4, 2); fence(); if (park) *reinterpret_cast<v4i *>(nb + wA1 + ks * 8192) = v4i{(int)up[4], (int)up[5], (int)up[6], (int)up[7]}; fence();
                 if ((W4_ABLATE & 8) || NF - 1 < nfr_k) {     // (wave-uniform: the tile may be narrower than this fragment)
 #pragma unroll
                     for (int l = 0; l < L; ++l) {
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
                         else mfma_i8_vgpr(accv[l][0], wf[NF - 1], afr[ks % D][l]);
                     }
                 }
-                if (park) issue_weight_piece(rsW2, sW2, nfr2, ks);
+                if (park) bst[ks % NF] = __builtin_amdgcn_raw_buffer_load_b128(rsW2, voffW, ks < nfr2 ? sW2 + ks * pieceW : OOB, 0);   // (OOB + i * pieceW stays out of bounds)
                 if (ks == NF && kt == KT - 1) park_sz(szbuf + (parity ^ 1) * 3 * C::BN);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -474,8 +474,17 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         const bool row_ok_e = active && rl_e < cur.rows_valid;
         const int t_e = row_ok_e ? cur.row0 + rl_e : 0;
         const float *sz = szbuf + parity * 3 * C::BN;
-        if constexpr (NVA > 0) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the VGPR-form instructions' results: no interlock with VALU readers
-        auto acc_of = [&](int l, int j) -> const v16i & { return (NVA > 0 && j >= NF - NVF) ? accv[l][j - (NF - NVF) < 0 ? 0 : j - (NF - NVF)] : acc[l][j < NF - NVF ? j : 0]; };
+        // the matrix instructions' results have no interlock with the readers below (inline assembly on both sides)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        // One accumulator value as an integer in a VGPR.  The AGPR-resident accumulators are read by an explicit (volatile)
+        // v_accvgpr_read_b32 where the value is used: left to itself the compiler copies all 240 AGPRs into VGPRs at the top
+        // of the epilogue and spills the prefetch rings to make room.
+        auto acc_val = [&](int l, int j, int r) -> int {
+            if (NVA > 0 && j >= NF - NVF) return accv[l][j - (NF - NVF) < 0 ? 0 : j - (NF - NVF)][r];
+            int v;
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[l][j < NF - NVF ? j : 0][r]));
+            return v;
+        };
         // mode 0: plain tile; 1: residual pass -- park the float32 results in this lane's scratch slot (workgroup-private,
         // read back by the same lane in the next visit); 2: main pass after a residual pass -- add the parked values.
         // The accumulators are read in ONE place per path (per-mode copies of a loop get their common accumulator reads
@@ -492,7 +501,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
                 float tot = 0.0f;
 #pragma unroll
                 for (int l = L - 1; l >= 0; --l)
-                    tot = fmaf(tot, 256.0f, fmaf(-z4[c], rs[l], (float)acc_of(l, j)[4 * q + c]));
+                    tot = fmaf(tot, 256.0f, fmaf(-z4[c], rs[l], (float)acc_val(l, j, 4 * q + c)));
                 o[c] = (tot * d) * s4[c];
             }
         };
@@ -504,18 +513,27 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
             // front of the branch by the compiler -- all 288 registers at once.)
             float *orow = reinterpret_cast<float *>(out) + (size_t)t_e * N + cur.n0 + 4 * g_e;
             float *slot0 = res_scratch + ((size_t)blockIdx.x * C::NW + wave) * (NF * 1024) + lane_e * 4;
+            // (the scale / zero-point vectors of fragment j + 1 are read from LDS while fragment j is computed: read where
+            //  they are used, each of the 48 reads is followed by a full LDS round trip with nothing else to issue)
+            v4f sq[2][4], zq[2][4];
+            auto read_sz = [&](int j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c0 = j * 32 + 8 * q + 4 * g_e;
+                    sq[j & 1][q] = *reinterpret_cast<const v4f *>(sz + c0);
+                    zq[j & 1][q] = *reinterpret_cast<const v4f *>(sz + C::BN + c0);
+                }
+            };
+            read_sz(0);
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
                 __builtin_amdgcn_sched_barrier(0);           // (register pressure: no fragment's reads before its turn)
                 if (j >= nfr_c) continue;
+                if (j + 1 < NF) read_sz(j + 1);
+                __builtin_amdgcn_sched_barrier(0);
                 float o[4][4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c0 = j * 32 + 8 * q + 4 * g_e;
-                    const v4f s4 = *reinterpret_cast<const v4f *>(sz + c0);
-                    const v4f z4 = *reinterpret_cast<const v4f *>(sz + C::BN + c0);
-                    out4(j, q, s4, z4, o[q]);
-                }
+                for (int q = 0; q < 4; ++q) out4(j, q, sq[j & 1][q], zq[j & 1][q], o[q]);
                 if (fast) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)

@@ -28,6 +28,8 @@ int g_group_i8_min_rows = 40;          // ... from this many rows on for one mat
 int g_group_i8_min_rows_grouped = 8;   //     crossover 32..48), and from 8 rows per expert on for grouped calls (190 vs 230 us at 8 x 8 rows)
 int g_group_mfma = 1;                  // per-group scales: the float32 matrix-core kernel for batches (A/B hook below)
 int g_use_w4 = 1;                      // 3 limbs, > 64 rows per group: the one-wave-per-SIMD kernel (fql_gemm_w4.h) instead of the 8-wave 128 x 192 one (A/B hook below)
+int g_split_small = 0;                 // grouped w4 calls: small last remainders of a row group in a second, decode-size launch (A/B hook below;
+                                       // measured: skewed 198 -> 188 us, but an empty second launch costs even routing 4.8 us: off)
 int g_act_single_rows = 512;          // pre-pass: one row per workgroup up to this many padded rows (tuning hook below)
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -340,7 +342,7 @@ int launch_rows32_cfg(const Workspace &w, const uint8_t *packed, const float *sc
 template <int L, int NF, int KG, int BDEPTH, int NWAVES = 8>
 int launch_rows16_cfg(const Workspace &w, const uint8_t *packed, const float *scales, const float *zps, void *out,
                       int out_dtype, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT,
-                      int N, hipStream_t st)
+                      int N, hipStream_t st, int part = 0)
 {
     using C = Rows16Cfg<L, NF, KG, BDEPTH, NWAVES>;
     auto kern = gemm_i8_rows16_kernel<L, NF, KG, BDEPTH, NWAVES>;
@@ -348,7 +350,8 @@ int launch_rows16_cfg(const Workspace &w, const uint8_t *packed, const float *sc
     if (!ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), C::LDS_BYTES)) return FQL_ERR_LAUNCH;
     (void)hipGetLastError();                                 // a stale error of another library must not read as ours
     const int n_tiles = (N + C::BN - 1) / C::BN;
-    const int m_slots = (tpe == nullptr) ? (T + C::BM - 1) / C::BM : T / C::BM + E;
+    int m_slots = (tpe == nullptr) ? (T + C::BM - 1) / C::BM : T / C::BM + E;
+    if (part == 2 && m_slots > E * ((FQL_SPLIT_SMALL + C::BM - 1) / C::BM)) m_slots = E * ((FQL_SPLIT_SMALL + C::BM - 1) / C::BM);   // small remainders only
     const int cus = compute_units() * (8 / C::NW);          // persistent: one 8-wave or two 4-wave workgroups per CU
     const int groups = (tpe == nullptr) ? 1 : E;
     const long long m_even = (long long)groups * (((T + groups - 1) / groups + C::BM - 1) / C::BM);   // row blocks if evenly routed
@@ -358,14 +361,14 @@ int launch_rows16_cfg(const Workspace &w, const uint8_t *packed, const float *sc
     if (blocks <= 0 || blocks > 0x7fffffffLL) return FQL_ERR_BAD_SHAPE;
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, w.limbs, w.delta, w.rowsum,
-                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch, w.bias, n_alt);
+                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch, w.bias, n_alt, part);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
 // The one-wave-per-SIMD kernel: same tiles and column split as the wide kernel's 128 x 192 configuration.
 int launch_w4_cfg(int L, int nf, int depth, const Workspace &w, const uint8_t *packed, const float *scales, const float *zps,
                   void *out, int out_dtype, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT,
-                  int N, hipStream_t st)
+                  int N, hipStream_t st, int part = 0)
 {
     if (Kp < 2 * FQL_KB) return FQL_ERR_BAD_SHAPE;           // its pipeline runs two weight stages ahead
     const int BM = 128, BN = fql_w4_bn(L, nf);
@@ -386,6 +389,7 @@ int launch_w4_cfg(int L, int nf, int depth, const Workspace &w, const uint8_t *p
     a.tpe = tpe; a.offs = offs;
     a.E = E; a.T = T; a.K = K; a.Kp = Kp; a.MBT = MBT; a.N = N;
     a.n_tiles = n_tiles; a.m_slots = m_slots; a.n_alt = n_alt;
+    a.part = part;
     a.scratch = w.scratch; a.bias = w.bias;
     a.blocks = blocks; a.stream = st;
     const int rc = fql_w4_launch(L, nf, depth, a);
@@ -514,6 +518,23 @@ inline int choose_cfg(int L, int E, int T, int K, int N, bool grouped)
     return best;
 }
 
+// The 3-limb GEMM of the product path (fused entry points and fql_gemm_i8_f32 alike).
+int launch_product_gemm3(int cfg, const Workspace &w, const uint8_t *packed, const float *scales, const float *zps, void *out,
+                         int out_dtype, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT, int N,
+                         hipStream_t st)
+{
+    if (cfg == 301 && tpe != nullptr && g_split_small) {
+        // Skewed routing: a row group whose last 128-row tile holds <= 64 rows (a 12-row tail, a 24-row expert) would pay
+        // a whole tile of matrix work for it.  Those remainders go to a second, weight-streaming launch of the 16-row
+        // decode kernel (expert_part() in fql_common.h; the counts live on the device, so the launch is unconditional:
+        // one empty launch under even routing).  Same arithmetic, bit-identical rows.
+        const int rc = launch_w4_cfg(3, 6, 4, w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, st, 1);
+        if (rc != FQL_OK) return rc;
+        return launch_rows16_cfg<3, 4, 4, 1>(w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, st, 2);
+    }
+    return launch_gemm<3>(cfg, w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, st);
+}
+
 int run_mfma(int L, const void *x, int in_dtype, const int32_t *gather, int n_src, const uint8_t *packed,
              const float *scales, const float *zps, void *out, int out_dtype, const int32_t *tpe, const int32_t *offs,
              int E, int T, int K, int N, void *workspace, size_t workspace_bytes, hipStream_t st, bool gated = false,
@@ -546,7 +567,7 @@ int run_mfma(int L, const void *x, int in_dtype, const int32_t *gather, int n_sr
     }
     rc = launch_act_quant<3>(x, in_dtype, gather, n_src, w, T, K, Kp, MBT, zero_out, out_dtype, N, tpe, offs, E, st, gated);
     if (rc != FQL_OK) return rc;
-    return launch_gemm<3>(cfg, w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, st);
+    return launch_product_gemm3(cfg, w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, st);
 }
 
 int run_generic(const float *x, const uint8_t *packed, const float *scales, const float *zps, float *out,
@@ -1093,6 +1114,7 @@ static int gemm_i8_entry(int cfg, const int8_t *limbs, const float *delta, const
                          int K, int N, int precision, void *stream, void *scratch, size_t scratch_bytes)
 {
     const int L = limbs_of(precision);
+    const bool product_choice = cfg < 0;                     // the library's own tile choice (else: an explicit tuning id)
     if (L < 0) return FQL_ERR_BAD_PRECISION;
     if (E <= 0 || T < 0 || K <= 0 || N < 0) return FQL_ERR_BAD_SHAPE;
     if (K & 1) return FQL_ERR_ODD_K;
@@ -1127,6 +1149,7 @@ static int gemm_i8_entry(int cfg, const int8_t *limbs, const float *delta, const
         return launch_gemm<1>(cfg, w, packed, scales, zps, out, FQL_DTYPE_F32, tokens_per_expert, input_offsets, E, T, K, Kp, MBT, N, st);
     if (L == 2)
         return launch_gemm<2>(cfg, w, packed, scales, zps, out, FQL_DTYPE_F32, tokens_per_expert, input_offsets, E, T, K, Kp, MBT, N, st);
+    if (product_choice) return launch_product_gemm3(cfg, w, packed, scales, zps, out, FQL_DTYPE_F32, tokens_per_expert, input_offsets, E, T, K, Kp, MBT, N, st);
     return launch_gemm<3>(cfg, w, packed, scales, zps, out, FQL_DTYPE_F32, tokens_per_expert, input_offsets, E, T, K, Kp, MBT, N, st);
 }
 
@@ -1177,6 +1200,7 @@ FQL_API int fql_tune_chosen_cfg(int precision, int E, int T, int K, int N, int g
     if (L < 0) return -1;
     return is_f8(precision) ? choose_cfg_f8(E, T, N, grouped != 0) : choose_cfg(L, E, T, K, N, grouped != 0);
 }
+FQL_API int fql_tune_set_split_small(int on) { const int old = g_split_small; g_split_small = on ? 1 : 0; return old; }
 FQL_API int fql_tune_set_w4(int on) { const int old = g_use_w4; g_use_w4 = on ? 1 : 0; return old; }
 
 

@@ -114,3 +114,39 @@ def test_w4_headline_shape_bit_identical(fq):
         outs = run_cfgs(ops, [0] + w4_ids(), limbs, delta, rowsum, dP, dS, dZ, cnt, offs, E, T, K, N)
         for cfg in w4_ids():
             assert torch.equal(outs[cfg], outs[0]), f"configuration {cfg} differs from the wide kernel ({counts})"
+
+
+@pytest.mark.parametrize("counts", [
+    [485, 230, 140, 90, 45, 24, 6, 4],                       # the reference's default "skewed" routing at 512 tokens, top-2
+    [128, 129, 192, 193, 64, 65, 1, 0],                      # remainders 0, 1, 64 (split off) and 65 (kept)
+    [300, 0, 0, 17, 256, 63, 700, 5],
+])
+def test_split_launch_equals_single_launch(fq, counts):
+    """Product path for grouped 3-limb calls = the wide launch without each expert's small last remainder + a decode-size
+    launch for those remainders (expert_part(), csrc/fql_common.h).  Every row must carry the bits of the single-launch
+    wide kernel, and the small groups must match the float64 oracle."""
+    from fused_int4_amd import ops, _native
+    lib = _native.lib()
+    old = lib.fql_tune_set_split_small(1)
+    try:
+        _split_case(ops, counts)
+    finally:
+        lib.fql_tune_set_split_small(old)
+
+
+def _split_case(ops, counts):
+    E, N, K = len(counts), 1100, 1024
+    P, S, Z, x, cnt, offs = make_moe(E, N, K, counts, 99 + sum(counts), heavy_every=11)
+    T = x.shape[0]
+    dP, dS, dZ, dx, dc, do = dev(P), dev(S), dev(Z), dev(x), dev(cnt), dev(offs)
+    limbs, delta, rowsum = ops.act_quant(dx, precision="exact", tokens_per_expert=dc, input_offsets=do)
+    ref_out = run_cfgs(ops, [0], limbs, delta, rowsum, dP, dS, dZ, dc, do, E, T, K, N)[0]
+    prod = ops.moe_forward(dP, dS, dZ, dx, None, dc, do)
+    assert torch.equal(prod, ref_out)
+    two_phase = ops.gemm_i8(limbs, delta, rowsum, dP, dS, dZ, dc, do, precision="exact")
+    assert torch.equal(two_phase, ref_out)
+    ref = C.moe_grouped(P, S, Z, x, cnt, offs)
+    got = prod.cpu().numpy()
+    for e, (o, c) in enumerate(zip(offs, cnt)):
+        if 0 < c <= 64:
+            assert rel_fro(got[o:o + c], ref[o:o + c]) < EXACT_REL_FRO, e
