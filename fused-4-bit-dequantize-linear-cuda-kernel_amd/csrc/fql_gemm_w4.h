@@ -99,12 +99,21 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, g = lane >> 5;
-    const int wm = wave;                                     // this wave's 32-row block of every tile
+    // ---- what a wave does in a tile depends on the tile's rows (short row groups: skewed routing, the tail of a group):
+    //        > 64 rows: wave w owns row block w and all NF fragments                      (18 matrix instructions per k-step)
+    //      33..64 rows: wave w owns row block w & 1 and fragments 3 (w >> 1) .. + 2          (9)
+    //       <= 32 rows: waves 0..2 own row block 0 and fragments 2 w, 2 w + 1; wave 3 idles  (6)
+    //      so a short tile costs its weight stream and staging, not a 128-row tile's matrix work.  The integer sums of an
+    //      output do not depend on which wave made them: bit-identical.
+    auto tile_class = [&](const GemmTile &tp) -> int { return tp.rows_valid > 64 ? 4 : (tp.rows_valid > 32 ? 2 : 1); };
+    auto wave_rb = [&](int cls) -> int { return cls == 4 ? wave : (cls == 2 ? (wave & 1) : 0); };
+    auto wave_fbase = [&](int cls) -> int { return cls == 4 ? 0 : (cls == 2 ? 3 * (wave >> 1) : 2 * wave); };
+    auto wave_has_work = [&](int cls) -> bool { return cls != 1 || wave < 3; };
 
     // ---- column tiling: exactly the wide kernel's (fql_gemm_i8.h): the N / 32 fragments of a row block dealt as evenly
     //      as possible over the tile count picked here from the real row-block count
     int n_tiles = n_tiles_min;
-    int n_real = m_slots * n_tiles;
+    int n_real = 0;
     const int n_frag = (N + 31) >> 5;
     auto pick_tiles = [&](int m_tiles) {
         if (n_tiles_alt <= 0) return;
@@ -114,26 +123,93 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         const float cb = rb * (float)(n_frag + n_tiles_alt) * (float)n_tiles_min;
         if (cb < ca) n_tiles = n_tiles_alt;
     };
+    // ---- row tiles, ordered by COST: first every expert's tiles with more than 64 rows, then the 33..64-row tails, then
+    //      the tails of at most 32 rows (a short tile costs about 0.6 of a full one).  A workgroup walks tile ids
+    //      blockIdx, + gridDim, ..., so every workgroup gets its share of the expensive tiles first and the cheap ones fill
+    //      the last round; inside each of the three groups an XCD still owns a contiguous range of tile ids (its
+    //      workgroups share an expert's activation panel in that XCD's L2).  Under even routing there is one group and
+    //      the order is the wide kernel's.
+    struct RowGroups { int lo, cnt, pad_excl, nbig, big_excl, c2, c2_excl, c1, c1_excl; };
+    auto row_groups = [&](int base, int &carry_pad, int &cb, int &c2, int &c1) -> RowGroups {
+        RowGroups r;
+        r.lo = 0; r.cnt = 0;
+        if (base + lane < E) expert_range(tpe, offs, base + lane, T, r.lo, r.cnt);
+        const int pad = (r.cnt + FQL_MB - 1) / FQL_MB * FQL_MB;
+        const int lo0 = r.lo;
+        expert_part(part, r.lo, r.cnt);
+        const int full = r.cnt / C::BM, rem = r.cnt - full * C::BM;
+        r.nbig = full + (rem > 64 ? 1 : 0);
+        r.c2 = (rem > 32 && rem <= 64) ? 1 : 0;
+        r.c1 = (rem >= 1 && rem <= 32) ? 1 : 0;
+        const int pad_incl = wave_incl_scan(pad, lane), big_incl = wave_incl_scan(r.nbig, lane);
+        const int c2_incl = wave_incl_scan(r.c2, lane), c1_incl = wave_incl_scan(r.c1, lane);
+        r.pad_excl = carry_pad + pad_incl - pad + (r.lo - lo0);
+        r.big_excl = cb + big_incl - r.nbig;
+        r.c2_excl = c2 + c2_incl - r.c2;
+        r.c1_excl = c1 + c1_incl - r.c1;
+        carry_pad += __shfl(pad_incl, 63, 64);
+        cb += __shfl(big_incl, 63, 64);
+        c2 += __shfl(c2_incl, 63, 64);
+        c1 += __shfl(c1_incl, 63, 64);
+        return r;
+    };
+    int MB = m_slots, MC2 = 0, MC1 = 0;                      // row tiles per cost group
     if (tpe != nullptr) {
-        int cp = 0, ct = 0;
-        for (int base = 0; base < E; base += 64) (void)expert_chunk(tpe, offs, E, T, C::BM, base, lane, cp, ct, part);
-        const int m_tiles = __builtin_amdgcn_readfirstlane(ct < m_slots ? ct : m_slots);
-        pick_tiles(m_tiles);
-        n_real = m_tiles * n_tiles;
+        int cp = 0, cb = 0, c2 = 0, c1 = 0;
+        for (int base = 0; base < E; base += 64) (void)row_groups(base, cp, cb, c2, c1);
+        MB = __builtin_amdgcn_readfirstlane(cb); MC2 = __builtin_amdgcn_readfirstlane(c2); MC1 = __builtin_amdgcn_readfirstlane(c1);
+        if (MB + MC2 + MC1 > m_slots) {                      // overlapping ranges: stay inside the plan
+            MB = MB < m_slots ? MB : m_slots;
+            MC2 = MC2 < m_slots - MB ? MC2 : m_slots - MB;
+            MC1 = MC1 < m_slots - MB - MC2 ? MC1 : m_slots - MB - MC2;
+        }
+        if (MC2 + MC1 == 0) pick_tiles(MB);
+        else if (n_tiles_alt > 0) {
+            // mixed costs: replay the walk for both tile counts -- the expensive tiles fill whole rounds, the cheap ones
+            // (0.6 of a full tile) continue where those end -- and take the one whose busiest workgroup carries less
+            auto busiest = [&](int t) -> float {
+                const int G = (int)gridDim.x;
+                const int nb = MB * t, ns = (MC2 + MC1) * t;
+                const int R = nb % G;                        // workgroups with one expensive tile more
+                const int sq = ns / G, sr = ns - sq * G;     // cheap tiles: sq each, one more for sr workgroups from R on
+                const float cb = (float)n_frag / (float)t + 1.0f, cs = 0.6f * cb;
+                const float hi = (float)(nb / G + (R > 0 ? 1 : 0)), lo = (float)(nb / G);
+                // workgroups [0, R): hi expensive; [R, G): lo expensive; extra cheap tile for [R, R + sr) wrapping to [0, R + sr - G)
+                const int wrap = R + sr - G;                 // > 0: the extra cheap tiles reach the workgroups with hi
+                float m = lo * cb + (float)(sq + (sr > 0 ? 1 : 0)) * cs;
+                const float mh = hi * cb + (float)(sq + (wrap > 0 ? 1 : 0)) * cs;
+                if (R > 0 && mh > m) m = mh;
+                return m;
+            };
+            if (busiest(n_tiles_alt) < busiest(n_tiles_min)) n_tiles = n_tiles_alt;
+        }
     } else {
         pick_tiles(m_slots);
-        n_real = m_slots * n_tiles;
     }
     n_tiles = __builtin_amdgcn_readfirstlane(n_tiles);
-    n_real = __builtin_amdgcn_readfirstlane(n_real);
+    const int n_big = MB * n_tiles, n_c2 = MC2 * n_tiles, n_c1 = MC1 * n_tiles;
+    n_real = __builtin_amdgcn_readfirstlane(n_big + n_c2 + n_c1);
     if ((int)blockIdx.x >= n_real) return;
     const int f_base = n_frag / n_tiles, f_rem = n_frag - f_base * n_tiles;
+
+    // slots [lo, lo + cnt) of the walk order -> tile ids [lo, lo + cnt), the slots of one XCD (slot & 7: blocks b and b + 8
+    // share an XCD, and gridDim is a multiple of 8) getting a contiguous range.  Speed only, never correctness.
+    auto xcd_range_remap = [&](int vb, int lo, int cnt) -> int {
+        auto upto = [&](int v, int x) -> int { return v <= x ? 0 : ((v - 1 - x) >> 3) + 1; };   // slots < v with slot & 7 == x
+        const int x = vb & 7;
+        int basex = 0;
+        for (int xx = 0; xx < 8; ++xx)
+            if (xx < x) basex += upto(lo + cnt, xx) - upto(lo, xx);
+        return lo + basex + (upto(vb, x) - upto(lo, x));
+    };
 
     auto tile_params = [&](int vb) -> GemmTile {
         GemmTile tp = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (vb >= n_real) return tp;
-        const int tile = xcd_remap(vb, n_real);
-        const int ms = tile / n_tiles;
+        const int grp = vb < n_big ? 0 : (vb < n_big + n_c2 ? 1 : 2);
+        const int glo = grp == 0 ? 0 : (grp == 1 ? n_big : n_big + n_c2);
+        const int tile = xcd_range_remap(vb, glo, grp == 0 ? n_big : (grp == 1 ? n_c2 : n_c1)) - glo;
+        const int ms = tile / n_tiles;                       // row tile inside its cost group
         tp.nt = tile - ms * n_tiles;
         tp.nfr = f_base + (tp.nt < f_rem ? 1 : 0);
         tp.n0 = (tp.nt * f_base + (tp.nt < f_rem ? tp.nt : f_rem)) * 32;
@@ -142,18 +218,21 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
             tp.rows_valid = T - tp.row0;
             tp.ok = 1;
         } else {
-            int cp = 0, ct = 0;
+            int cp = 0, cb = 0, c2 = 0, c1 = 0;
             for (int base = 0; base < E && !tp.ok; base += 64) {
-                const ExpertLane x = expert_chunk(tpe, offs, E, T, C::BM, base, lane, cp, ct, part);
-                const unsigned long long hit = __ballot(ms >= x.tile_excl && ms < x.tile_excl + x.tiles);
+                const RowGroups x = row_groups(base, cp, cb, c2, c1);
+                const bool mine = grp == 0 ? (ms >= x.big_excl && ms < x.big_excl + x.nbig)
+                                           : (grp == 1 ? (x.c2 && ms == x.c2_excl) : (x.c1 && ms == x.c1_excl));
+                const unsigned long long hit = __ballot(mine);
                 if (hit) {
                     const int src = __ffsll((long long)hit) - 1;
                     const int lo = __shfl(x.lo, src, 64), cnt = __shfl(x.cnt, src, 64);
-                    const int te = __shfl(x.tile_excl, src, 64), pe = __shfl(x.pad_excl, src, 64);
+                    const int be = __shfl(x.big_excl, src, 64), pe = __shfl(x.pad_excl, src, 64);
+                    const int slice = grp == 0 ? ms - be : cnt / C::BM;       // the tail is the slice after the full ones
                     tp.e = base + src;
-                    tp.row0 = lo + (ms - te) * C::BM;
-                    tp.prow0 = pe + (ms - te) * C::BM;
-                    tp.rows_valid = cnt - (ms - te) * C::BM;
+                    tp.row0 = lo + slice * C::BM;
+                    tp.prow0 = pe + slice * C::BM;
+                    tp.rows_valid = cnt - slice * C::BM;
                     tp.ok = 1;
                 }
             }
@@ -231,8 +310,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
     // scalar offsets of a tile's operands (OOB: the loads read zero and move nothing)
     auto w_base = [&](const GemmTile &tp) -> int { return tp.ok ? tp.n0 * (K >> 1) : OOB; };
     auto a_base = [&](const GemmTile &tp) -> int {
-        const bool act = tp.ok && wm * FQL_MB < tp.rows_valid;
-        return act ? ((tp.prow0 >> 5) + wm) * 8192 + ((RES && tp.rp) ? L * a_limb : 0) : OOB;
+        const int cls = tile_class(tp), rb = wave_rb(cls);
+        const bool act = tp.ok && wave_has_work(cls) && rb * FQL_MB < tp.rows_valid;
+        return act ? ((tp.prow0 >> 5) + rb) * 8192 + ((RES && tp.rp) ? L * a_limb : 0) : OOB;
     };
     auto issue_weights = [&](const __amdgpu_buffer_rsrc_t rs, int sW, int nfr) {
 #pragma unroll
@@ -274,10 +354,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         for (int i = 0; i < C::SZN; ++i)
             if (tid + i * C::THREADS < 3 * C::BN) sz[tid + i * C::THREADS] = szr[i];
     };
-    auto read_frags = [&](const char *buf, int ks) {         // all NF fragments of k-step ks
-        const char *p = buf + (rF0 ^ frag_xor(ks));
+    // the fragments a visit expects in wf[] when its first k-step starts: the first four of its wave's range, k-step 0 of
+    // the stage in `buf` (every slot plan reads its later ones itself).  The plans prefetch the coming step's fragments
+    // with the CURRENT tile's fragment range, so at a visit boundary they are read again for the next tile's.
+    auto read_first_frags = [&](const char *buf, int fb) {
+        const char *p = buf + fb * 8192 + (rF0 ^ frag_xor(0));
 #pragma unroll
-        for (int j = 0; j < NF; ++j) wf[j] = *reinterpret_cast<const v4i *>(p + j * 8192);
+        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const v4i *>(p + j * 8192);
     };
 
     // ---- kernel prologue: the state every visit starts from
@@ -305,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         park_sz(szbuf);
         issue_weights(rs, sW == OOB ? OOB : sW + (FQL_KB / 2), cur.nfr);
         __syncthreads();
-        read_frags(lds, 0);
+        read_first_frags(lds, wave_fbase(tile_class(cur)));
     }
 
     int ev = 0; (void)ev;
@@ -313,7 +396,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         FQL_W4STAMP(ev++, 1);
         FQL_W4STAMP(ev++, 0);
         const bool rpass = RES && cur.rp != 0;
-        const bool active = cur.ok && wm * FQL_MB < cur.rows_valid;
+        const int cls = tile_class(cur), wm = wave_rb(cls), fbase = wave_fbase(cls);
+        const bool active = cur.ok && wave_has_work(cls) && wm * FQL_MB < cur.rows_valid;
         // ---- the visit after this one: the main pass of the same tile after its residual pass, else the next tile
         GemmTile nxt;
         if (rpass) { nxt = cur; nxt.rp = 0; nxt.ad = 1; }
@@ -346,10 +430,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
 
         using T_ = std::true_type;
         using F_ = std::false_type;
-        constexpr int NVA = NVF;
+        auto visit_body = [&](auto nact_tag) {
+        constexpr int NACT = decltype(nact_tag)::value;      // fragments a wave holds in this kind of tile
+        constexpr int NVA = (NACT == NF) ? NVF : 0;
         const int nfr_k = cur.nfr;
-        v16i acc[L][NF - NVF > 0 ? NF - NVF : 1];
-        v16i accv[L][NVF > 0 ? NVF : 1];
+        v16i acc[L][NACT - NVA > 0 ? NACT - NVA : 1];
+        v16i accv[L][NVA > 0 ? NVA : 1];
 
         // ---- one 256-k stage.  FIRST: the accumulators start from the instruction's zero operand.
         auto stage = [&](auto first_tag, int kt) {
@@ -395,8 +481,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
                 //  of a full register file and end up in scratch)
                 int rFo = rF0;
                 asm volatile("" : "+v"(rFo));
-                const char *fc = sb + (rFo ^ frag_xor(ks));                                 // this step's fragments
-                const char *fp = ((ks == KS - 1) ? nb : sb) + (rFo ^ frag_xor((ks + 1) & 7));   // the coming step's
+                const char *fc = sb + fbase * 8192 + (rFo ^ frag_xor(ks));                  // this step's fragments (from the wave's first)
+                const char *fp = ((ks == KS - 1) ? nb : sb) + fbase * 8192 + (rFo ^ frag_xor((ks + 1) & 7));   // the coming step's
                 const bool park = ks < NF && !(W4_ABLATE & 1);
                 uint32_t up[8];
                 auto mm = [&](int j, int l) {                // one matrix instruction of fragment j < NF - NVF
@@ -421,33 +507,62 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
                     unpack8((uint32_t)bst[ks % NF][i], up[2 * i], up[2 * i + 1]);
                     asm volatile("" : "+v"(up[2 * i]), "+v"(up[2 * i + 1]));              // pin the unpack to this slot
                 };
-                static_assert(NF == 6 && L == 3 && NVF == 1, "the slot plan below is written for 6 fragments x 3 limbs, the last fragment in VGPRs");
-                mm(0, 0); fence(); frag(fc, 5); fence();
-                mm(0, 1); fence(); frag(fc, 4); fence();
-                mm(0, 2); fence(); refill(0); fence();
-                if (ks == KS - 1) {
-                    // every wave has parked the next stage (steps 0..NF-1) and holds the last fragments of this one
-                    wait_lgkmcnt0();
-                    __builtin_amdgcn_s_barrier();
-                }
-                mm(1, 0); fence(); frag(fp, 0); fence();
-                mm(1, 1); fence(); refill(1); fence();
-                mm(1, 2); fence(); refill(2); fence();
-                mm(2, 0); fence(); frag(fp, 1); fence();
-                mm(2, 1); fence(); unpack(0); fence();
-                mm(2, 2); fence(); unpack(1); fence();
-                mm(3, 0); fence(); frag(fp, 2); fence();
-                mm(3, 1); fence(); unpack(2); fence();
-                mm(3, 2); fence(); unpack(3); fence();
-                mm(4, 0); fence(); frag(fp, 3); fence();
-                mm(4, 1); fence(); if (park) *reinterpret_cast<v4i *>(nb + wA0 + ks * 8192) = v4i{(int)up[0], (int)up[1], (int)up[2], (int)up[3]}; fence();
-                mm(4, 2); fence(); if (park) *reinterpret_cast<v4i *>(nb + wA1 + ks * 8192) = v4i{(int)up[4], (int)up[5], (int)up[6], (int)up[7]}; fence();
-                if ((W4_ABLATE & 8) || NF - 1 < nfr_k) {     // (wave-uniform: the tile may be narrower than this fragment)
-#pragma unroll
-                    for (int l = 0; l < L; ++l) {
-                        if (FIRST && ks == 0) mfma_i8_vgpr_zero(accv[l][0], wf[NF - 1], afr[ks % D][l]);
-                        else mfma_i8_vgpr(accv[l][0], wf[NF - 1], afr[ks % D][l]);
+                static_assert(NF == 6 && L == 3 && NVF == 1, "the slot plans below are written for 6 fragments x 3 limbs, the last fragment in VGPRs");
+                auto park0 = [&]() { if (park) *reinterpret_cast<v4i *>(nb + wA0 + ks * 8192) = v4i{(int)up[0], (int)up[1], (int)up[2], (int)up[3]}; };
+                auto park1 = [&]() { if (park) *reinterpret_cast<v4i *>(nb + wA1 + ks * 8192) = v4i{(int)up[4], (int)up[5], (int)up[6], (int)up[7]}; };
+                auto stage_barrier = [&]() {
+                    if (ks == KS - 1) {
+                        // every wave has parked the next stage (steps 0..NF-1) and holds the last fragments of this one
+                        wait_lgkmcnt0();
+                        __builtin_amdgcn_s_barrier();
                     }
+                };
+                if constexpr (NACT == 6) {
+                    mm(0, 0); fence(); frag(fc, 5); fence();
+                    mm(0, 1); fence(); frag(fc, 4); fence();
+                    mm(0, 2); fence(); refill(0); fence();
+                    stage_barrier();
+                    mm(1, 0); fence(); frag(fp, 0); fence();
+                    mm(1, 1); fence(); refill(1); fence();
+                    mm(1, 2); fence(); refill(2); fence();
+                    mm(2, 0); fence(); frag(fp, 1); fence();
+                    mm(2, 1); fence(); unpack(0); fence();
+                    mm(2, 2); fence(); unpack(1); fence();
+                    mm(3, 0); fence(); frag(fp, 2); fence();
+                    mm(3, 1); fence(); unpack(2); fence();
+                    mm(3, 2); fence(); unpack(3); fence();
+                    mm(4, 0); fence(); frag(fp, 3); fence();
+                    mm(4, 1); fence(); park0(); fence();
+                    mm(4, 2); fence(); park1(); fence();
+                    if ((W4_ABLATE & 8) || NF - 1 < nfr_k) {     // (wave-uniform: the tile may be narrower than this fragment)
+#pragma unroll
+                        for (int l = 0; l < L; ++l) {
+                            if (FIRST && ks == 0) mfma_i8_vgpr_zero(accv[l][0], wf[NF - 1], afr[ks % D][l]);
+                            else mfma_i8_vgpr(accv[l][0], wf[NF - 1], afr[ks % D][l]);
+                        }
+                    }
+                } else if constexpr (NACT == 3) {            // 33..64 rows: 9 matrix instructions, the same staging work
+                    mm(0, 0); fence(); frag(fc, 2); fence();
+                    mm(0, 1); fence(); refill(0); fence();
+                    mm(0, 2); fence(); refill(1); fence();
+                    stage_barrier();
+                    mm(1, 0); fence(); frag(fp, 0); fence();
+                    mm(1, 1); fence(); refill(2); fence();
+                    mm(1, 2); fence(); unpack(0); unpack(1); fence();
+                    mm(2, 0); fence(); frag(fp, 1); fence();
+                    mm(2, 1); fence(); unpack(2); unpack(3); fence();
+                    mm(2, 2); fence(); park0(); fence();
+                    park1();
+                } else {                                     // <= 32 rows: 6 matrix instructions
+                    static_assert(NACT == 2, "tile classes: 6, 3 or 2 fragments per wave");
+                    mm(0, 0); fence(); frag(fc, 1); fence();
+                    mm(0, 1); fence(); refill(0); fence();
+                    mm(0, 2); fence(); refill(1); fence();
+                    stage_barrier();
+                    mm(1, 0); fence(); frag(fp, 0); fence();
+                    mm(1, 1); fence(); refill(2); unpack(0); fence();
+                    mm(1, 2); fence(); unpack(1); unpack(2); fence();
+                    unpack(3); park0(); park1();
                 }
                 if (park) bst[ks % NF] = __builtin_amdgcn_raw_buffer_load_b128(rsW2, voffW, ks < nfr2 ? sW2 + ks * pieceW : OOB, 0);   // (OOB + i * pieceW stays out of bounds)
                 if (ks == NF && kt == KT - 1) park_sz(szbuf + (parity ^ 1) * 3 * C::BN);
@@ -462,6 +577,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         stage(T_{}, 0);
         for (int kt = 1; kt < KT; ++kt) stage(F_{}, kt);
         FQL_W4STAMP(ev++, 0);
+        read_first_frags(lds + (fs & 1) * C::W_STAGE, wave_fbase(tile_class(nxt)));   // (lands under the epilogue)
 
         // ---- epilogue: identical arithmetic to gemm_i8_kernel (the weights are the matrix instruction's A operand, so a
         //      lane owns ONE output row t and registers 4q..4q+3 are 4 consecutive output columns)
@@ -480,7 +596,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         // v_accvgpr_read_b32 where the value is used: left to itself the compiler copies all 240 AGPRs into VGPRs at the top
         // of the epilogue and spills the prefetch rings to make room.
         auto acc_val = [&](int l, int j, int r) -> int {
-            if (NVA > 0 && j >= NF - NVF) return accv[l][j - (NF - NVF) < 0 ? 0 : j - (NF - NVF)][r];
+            if (NVA > 0 && j >= NF - NVF) return accv[l][0][r];
             int v;
             asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[l][j < NF - NVF ? j : 0][r]));
             return v;
@@ -494,7 +610,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         float rs[L];
 #pragma unroll
         for (int l = 0; l < L; ++l) rs[l] = (float)rsi[l];
-        const int nfr_c = cur.nfr < NF ? cur.nfr : NF;
+        const int nfr_c = cur.nfr - fbase < 0 ? 0 : (cur.nfr - fbase < NACT ? cur.nfr - fbase : NACT);   // this wave's fragments that exist
         auto out4 = [&](int j, int q, const v4f &s4, const v4f &z4, float (&o)[4]) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -505,43 +621,41 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
                 o[c] = (tot * d) * s4[c];
             }
         };
-        const bool fast = mode == 0 && vec && out_kind == 0 && bias == nullptr && cur.n0 + nfr_c * 32 <= N;
+        const bool fast = mode == 0 && vec && out_kind == 0 && bias == nullptr && cur.n0 + (fbase + nfr_c) * 32 <= N &&
+                          (size_t)T * (size_t)N < ((size_t)1 << 29);      // (32-bit byte offsets into `out`)
         if (row_ok_e && !(W4_ABLATE & 16)) {
             // One fragment (32 columns = 16 outputs of this lane) at a time: all its arithmetic as straight-line code, then
             // ONE branch on how to store -- the common case (float32 outputs, whole 16-byte stores, every column inside N)
             // or the general one.  (Two copies of the arithmetic, one per case, get their accumulator reads hoisted in
             // front of the branch by the compiler -- all 288 registers at once.)
-            float *orow = reinterpret_cast<float *>(out) + (size_t)t_e * N + cur.n0 + 4 * g_e;
+            const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((size_t)T * N * 4), 0x00020000);
+            const int ovoff = (t_e * N + cur.n0 + fbase * 32 + 4 * g_e) * 4;
             float *slot0 = res_scratch + ((size_t)blockIdx.x * C::NW + wave) * (NF * 1024) + lane_e * 4;
-            // (the scale / zero-point vectors of fragment j + 1 are read from LDS while fragment j is computed: read where
-            //  they are used, each of the 48 reads is followed by a full LDS round trip with nothing else to issue)
-            v4f sq[2][4], zq[2][4];
-            auto read_sz = [&](int j) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c0 = j * 32 + 8 * q + 4 * g_e;
-                    sq[j & 1][q] = *reinterpret_cast<const v4f *>(sz + c0);
-                    zq[j & 1][q] = *reinterpret_cast<const v4f *>(sz + C::BN + c0);
-                }
-            };
-            read_sz(0);
-#pragma unroll
-            for (int j = 0; j < NF; ++j) {
+            for (int j = 0; j < NACT; ++j) {
                 __builtin_amdgcn_sched_barrier(0);           // (register pressure: no fragment's reads before its turn)
                 if (j >= nfr_c) continue;
-                if (j + 1 < NF) read_sz(j + 1);
-                __builtin_amdgcn_sched_barrier(0);
                 float o[4][4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) out4(j, q, sq[j & 1][q], zq[j & 1][q], o[q]);
+                for (int q = 0; q < 4; ++q) {
+                    const int c0 = (fbase + j) * 32 + 8 * q + 4 * g_e;
+                    const v4f s4 = *reinterpret_cast<const v4f *>(sz + c0);
+                    const v4f z4 = *reinterpret_cast<const v4f *>(sz + C::BN + c0);
+                    out4(j, q, s4, z4, o[q]);
+                }
                 if (fast) {
+                    // (buffer stores: ONE 32-bit offset register per lane, fragment and quad in the scalar offset -- 64-bit
+                    //  store pointers kept across the fragments were spilled, and every scratch reload is a vmcnt(0) wait
+                    //  behind the next tile's prefetch)
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<v4f *>(orow + j * 32 + 8 * q) = v4f{o[q][0], o[q][1], o[q][2], o[q][3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(v4i{__builtin_bit_cast(int, o[q][0]), __builtin_bit_cast(int, o[q][1]),
+                                                                   __builtin_bit_cast(int, o[q][2]), __builtin_bit_cast(int, o[q][3])},
+                                                               rsO, ovoff, (j * 32 + 8 * q) * 4, 0);
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int c0 = j * 32 + 8 * q + 4 * g_e;
+                        const int c0 = (fbase + j) * 32 + 8 * q + 4 * g_e;
                         if (RES && mode == 1) {
                             *reinterpret_cast<v4f *>(slot0 + (j * 4 + q) * 256) = v4f{o[q][0], o[q][1], o[q][2], o[q][3]};
                         } else {
@@ -562,6 +676,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        };   // visit_body
+        // (one copy of K loop + epilogue per tile class, each with its own accumulators: a fragment skipped under a branch
+        //  inside ONE copy turns the accumulators into phi nodes and the compiler then spills whole tuples around the epilogue)
+        if (cls == 4) visit_body(std::integral_constant<int, 6>{});
+        else if (cls == 2) visit_body(std::integral_constant<int, 3>{});
+        else visit_body(std::integral_constant<int, 2>{});
         FQL_W4STAMP(ev++, 0);
         FQL_W4STAMP(ev++, 1);
         if (!nxt.nt) break;                                  // past the last tile of this workgroup
