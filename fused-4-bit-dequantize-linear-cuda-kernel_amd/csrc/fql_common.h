@@ -160,37 +160,19 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane)
     return v;
 }
 
-// Split of an expert's rows between two launches (skewed routing: a row group whose last 128-row tile holds at most
-// FQL_SPLIT_SMALL rows pays a whole 128-row tile of matrix work for it).  part 0: all rows (every caller but the two
-// below); 1: the rows up to the last multiple of 128 when the remainder is small, else all (the wide launch); 2: only
-// that small remainder (the decode-size launch that follows).  The remainder starts at a multiple of 128 rows of its
-// expert, so it starts on a 32-row block of the limb workspace like the expert itself.
-#define FQL_SPLIT_TILE 128
-#define FQL_SPLIT_SMALL 64
-__device__ __forceinline__ void expert_part(int part, int &lo, int &cnt)
-{
-    if (part == 0) return;
-    const int rem = cnt % FQL_SPLIT_TILE;
-    const int small = (rem > 0 && rem <= FQL_SPLIT_SMALL) ? rem : 0;
-    if (part == 1) cnt -= small;
-    else { lo += cnt - small; cnt = small; }
-}
-
 // Processes experts [base, base + 64); carry_pad / carry_tile are the totals of the experts before `base`
 // and are advanced to include this chunk.
 __device__ __forceinline__ ExpertLane expert_chunk(const int32_t *tpe, const int32_t *offs, int E, int T, int bm,
-                                                   int base, int lane, int &carry_pad, int &carry_tile, int part = 0)
+                                                   int base, int lane, int &carry_pad, int &carry_tile)
 {
     ExpertLane r;
     r.lo = 0; r.cnt = 0;
     if (base + lane < E) expert_range(tpe, offs, base + lane, T, r.lo, r.cnt);
-    const int pad = (r.cnt + FQL_MB - 1) / FQL_MB * FQL_MB;       // (the workspace layout follows the WHOLE expert)
-    const int lo0 = r.lo;
-    expert_part(part, r.lo, r.cnt);
+    const int pad = (r.cnt + FQL_MB - 1) / FQL_MB * FQL_MB;
     r.tiles = (r.cnt + bm - 1) / bm;
     const int pad_incl = wave_incl_scan(pad, lane);
     const int tile_incl = wave_incl_scan(r.tiles, lane);
-    r.pad_excl = carry_pad + pad_incl - pad + (r.lo - lo0);
+    r.pad_excl = carry_pad + pad_incl - pad;
     r.tile_excl = carry_tile + tile_incl - r.tiles;
     carry_pad += __shfl(pad_incl, 63, 64);
     carry_tile += __shfl(tile_incl, 63, 64);

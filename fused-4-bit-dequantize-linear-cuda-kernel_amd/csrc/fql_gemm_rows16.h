@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void gemm_i8_rows16_kernel(
     const float *__restrict__ scales, const float *__restrict__ zps, void *__restrict__ out, int out_kind,
     const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
     int E, int T, int K, int Kp, int MBT, int N, int n_tiles_min, int m_slots, float *__restrict__ res_scratch,
-    const float *__restrict__ bias, int n_tiles_alt, int part)
+    const float *__restrict__ bias, int n_tiles_alt)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = Rows16Cfg<L, NF, KG, BDEPTH, NWAVES>;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void gemm_i8_rows16_kernel(
     if (tpe != nullptr) {
         int cp = 0, ct = 0;
         for (int base = 0; base < E; base += 64) {
-            const ExpertLane x = expert_chunk(tpe, offs, E, T, C::BM, base, lane, cp, ct, part);
+            const ExpertLane x = expert_chunk(tpe, offs, E, T, C::BM, base, lane, cp, ct);
             if (base == 0 && wave == 0) { s_lo[lane] = x.lo; s_cnt[lane] = x.cnt; s_tex[lane] = x.tile_excl; s_pex[lane] = x.pad_excl; }
         }
         const int m_tiles = __builtin_amdgcn_readfirstlane(ct < m_slots ? ct : m_slots);
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void gemm_i8_rows16_kernel(
             if (!tp.ok && E > 64) {
                 int cp = 0, ct = 0;
                 for (int base = 0; base < E && !tp.ok; base += 64) {
-                    const ExpertLane x = expert_chunk(tpe, offs, E, T, C::BM, base, lane, cp, ct, part);
+                    const ExpertLane x = expert_chunk(tpe, offs, E, T, C::BM, base, lane, cp, ct);
                     const unsigned long long hit = __ballot(ms >= x.tile_excl && ms < x.tile_excl + x.tiles);
                     if (hit && base > 0) {
                         const int src = __ffsll((long long)hit) - 1;

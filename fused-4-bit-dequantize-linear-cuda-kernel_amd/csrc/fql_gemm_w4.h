@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
     const float *__restrict__ scales, const float *__restrict__ zps, void *__restrict__ out, int out_kind,
     const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
     int E, int T, int K, int Kp, int MBT, int N, int n_tiles_min, int m_slots, float *__restrict__ res_scratch,
-    const float *__restrict__ bias, int n_tiles_alt, int part)
+    const float *__restrict__ bias, int n_tiles_alt)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = W4Cfg<L, NF, DEPTH>;
@@ -135,15 +135,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         r.lo = 0; r.cnt = 0;
         if (base + lane < E) expert_range(tpe, offs, base + lane, T, r.lo, r.cnt);
         const int pad = (r.cnt + FQL_MB - 1) / FQL_MB * FQL_MB;
-        const int lo0 = r.lo;
-        expert_part(part, r.lo, r.cnt);
         const int full = r.cnt / C::BM, rem = r.cnt - full * C::BM;
         r.nbig = full + (rem > 64 ? 1 : 0);
         r.c2 = (rem > 32 && rem <= 64) ? 1 : 0;
         r.c1 = (rem >= 1 && rem <= 32) ? 1 : 0;
         const int pad_incl = wave_incl_scan(pad, lane), big_incl = wave_incl_scan(r.nbig, lane);
         const int c2_incl = wave_incl_scan(r.c2, lane), c1_incl = wave_incl_scan(r.c1, lane);
-        r.pad_excl = carry_pad + pad_incl - pad + (r.lo - lo0);
+        r.pad_excl = carry_pad + pad_incl - pad;
         r.big_excl = cb + big_incl - r.nbig;
         r.c2_excl = c2 + c2_incl - r.c2;
         r.c1_excl = c1 + c1_incl - r.c1;

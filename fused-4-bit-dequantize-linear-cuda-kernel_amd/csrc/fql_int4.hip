@@ -28,8 +28,6 @@ int g_group_i8_min_rows = 40;          // ... from this many rows on for one mat
 int g_group_i8_min_rows_grouped = 8;   //     crossover 32..48), and from 8 rows per expert on for grouped calls (190 vs 230 us at 8 x 8 rows)
 int g_group_mfma = 1;                  // per-group scales: the float32 matrix-core kernel for batches (A/B hook below)
 int g_use_w4 = 1;                      // 3 limbs, > 64 rows per group: the one-wave-per-SIMD kernel (fql_gemm_w4.h) instead of the 8-wave 128 x 192 one (A/B hook below)
-int g_split_small = 0;                 // grouped w4 calls: small last remainders of a row group in a second, decode-size launch (A/B hook below;
-                                       // measured: skewed 198 -> 188 us, but an empty second launch costs even routing 4.8 us: off)
 int g_act_single_rows = 512;          // pre-pass: one row per workgroup up to this many padded rows (tuning hook below)
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -187,9 +185,9 @@ inline bool valid_cfg(int cfg) { return (cfg >= 300 && cfg < 300 + FQL_NUM_W4) |
 }
 
 // The MFMA path addresses its operands through 32-bit buffer offsets.
-inline bool mfma_addressable(int L, int T, int E, int K, int N)
+inline bool mfma_addressable(int L, int T, int E, int K, int N, bool f8 = false)
 {
-    const size_t a = 2 * limb_bytes(L, T, E, padded_k(K));   // with the residual limb set
+    const size_t a = (has_residual(L, f8) ? 2 : 1) * limb_bytes(L, T, E, padded_k(K));   // (with the residual limb set where there is one)
     const size_t b = ((size_t)N + 256) * (size_t)(K >> 1);
     return a < ((size_t)1 << 31) && b < ((size_t)1 << 31);
 }
@@ -342,7 +340,7 @@ int launch_rows32_cfg(const Workspace &w, const uint8_t *packed, const float *sc
 template <int L, int NF, int KG, int BDEPTH, int NWAVES = 8>
 int launch_rows16_cfg(const Workspace &w, const uint8_t *packed, const float *scales, const float *zps, void *out,
                       int out_dtype, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT,
-                      int N, hipStream_t st, int part = 0)
+                      int N, hipStream_t st)
 {
     using C = Rows16Cfg<L, NF, KG, BDEPTH, NWAVES>;
     auto kern = gemm_i8_rows16_kernel<L, NF, KG, BDEPTH, NWAVES>;
@@ -350,8 +348,7 @@ int launch_rows16_cfg(const Workspace &w, const uint8_t *packed, const float *sc
     if (!ensure_lds_attr(attr, reinterpret_cast<const void *>(kern), C::LDS_BYTES)) return FQL_ERR_LAUNCH;
     (void)hipGetLastError();                                 // a stale error of another library must not read as ours
     const int n_tiles = (N + C::BN - 1) / C::BN;
-    int m_slots = (tpe == nullptr) ? (T + C::BM - 1) / C::BM : T / C::BM + E;
-    if (part == 2 && m_slots > E * ((FQL_SPLIT_SMALL + C::BM - 1) / C::BM)) m_slots = E * ((FQL_SPLIT_SMALL + C::BM - 1) / C::BM);   // small remainders only
+    const int m_slots = (tpe == nullptr) ? (T + C::BM - 1) / C::BM : T / C::BM + E;
     const int cus = compute_units() * (8 / C::NW);          // persistent: one 8-wave or two 4-wave workgroups per CU
     const int groups = (tpe == nullptr) ? 1 : E;
     const long long m_even = (long long)groups * (((T + groups - 1) / groups + C::BM - 1) / C::BM);   // row blocks if evenly routed
@@ -361,14 +358,14 @@ int launch_rows16_cfg(const Workspace &w, const uint8_t *packed, const float *sc
     if (blocks <= 0 || blocks > 0x7fffffffLL) return FQL_ERR_BAD_SHAPE;
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, w.limbs, w.delta, w.rowsum,
-                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch, w.bias, n_alt, part);
+                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch, w.bias, n_alt);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
 // The one-wave-per-SIMD kernel: same tiles and column split as the wide kernel's 128 x 192 configuration.
 int launch_w4_cfg(int L, int nf, int depth, const Workspace &w, const uint8_t *packed, const float *scales, const float *zps,
                   void *out, int out_dtype, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT,
-                  int N, hipStream_t st, int part = 0)
+                  int N, hipStream_t st)
 {
     if (Kp < 2 * FQL_KB) return FQL_ERR_BAD_SHAPE;           // its pipeline runs two weight stages ahead
     const int BM = 128, BN = fql_w4_bn(L, nf);
@@ -389,7 +386,6 @@ int launch_w4_cfg(int L, int nf, int depth, const Workspace &w, const uint8_t *p
     a.tpe = tpe; a.offs = offs;
     a.E = E; a.T = T; a.K = K; a.Kp = Kp; a.MBT = MBT; a.N = N;
     a.n_tiles = n_tiles; a.m_slots = m_slots; a.n_alt = n_alt;
-    a.part = part;
     a.scratch = w.scratch; a.bias = w.bias;
     a.blocks = blocks; a.stream = st;
     const int rc = fql_w4_launch(L, nf, depth, a);
@@ -518,23 +514,6 @@ inline int choose_cfg(int L, int E, int T, int K, int N, bool grouped)
     return best;
 }
 
-// The 3-limb GEMM of the product path (fused entry points and fql_gemm_i8_f32 alike).
-int launch_product_gemm3(int cfg, const Workspace &w, const uint8_t *packed, const float *scales, const float *zps, void *out,
-                         int out_dtype, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT, int N,
-                         hipStream_t st)
-{
-    if (cfg == 301 && tpe != nullptr && g_split_small) {
-        // Skewed routing: a row group whose last 128-row tile holds <= 64 rows (a 12-row tail, a 24-row expert) would pay
-        // a whole tile of matrix work for it.  Those remainders go to a second, weight-streaming launch of the 16-row
-        // decode kernel (expert_part() in fql_common.h; the counts live on the device, so the launch is unconditional:
-        // one empty launch under even routing).  Same arithmetic, bit-identical rows.
-        const int rc = launch_w4_cfg(3, 6, 4, w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, st, 1);
-        if (rc != FQL_OK) return rc;
-        return launch_rows16_cfg<3, 4, 4, 1>(w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, st, 2);
-    }
-    return launch_gemm<3>(cfg, w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, st);
-}
-
 int run_mfma(int L, const void *x, int in_dtype, const int32_t *gather, int n_src, const uint8_t *packed,
              const float *scales, const float *zps, void *out, int out_dtype, const int32_t *tpe, const int32_t *offs,
              int E, int T, int K, int N, void *workspace, size_t workspace_bytes, hipStream_t st, bool gated = false,
@@ -567,7 +546,7 @@ int run_mfma(int L, const void *x, int in_dtype, const int32_t *gather, int n_sr
     }
     rc = launch_act_quant<3>(x, in_dtype, gather, n_src, w, T, K, Kp, MBT, zero_out, out_dtype, N, tpe, offs, E, st, gated);
     if (rc != FQL_OK) return rc;
-    return launch_product_gemm3(cfg, w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, st);
+    return launch_gemm<3>(cfg, w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, st);
 }
 
 int run_generic(const float *x, const uint8_t *packed, const float *scales, const float *zps, float *out,
@@ -633,7 +612,7 @@ size_t fql_linear_workspace_bytes(int B, int K, int N, int precision)
 {
     (void)N;
     const int L = limbs_of(precision);
-    if (L < 0 || (B <= g_gemv_max_rows && !is_f8(precision)) || B <= 0 || K <= 0 || (K % 32) != 0) return 0;
+    if (L < 0 || B <= g_gemv_max_rows || B <= 0 || K <= 0 || (K % 32) != 0) return 0;   // (GEMV shapes use no workspace)
     Workspace w = carve(nullptr, L, B, 1, padded_k(K), has_residual(L, is_f8(precision)));
     return w.bytes;
 }
@@ -663,6 +642,9 @@ static int linear_f32_core(const float *x, const uint8_t *packed, const float *s
         return hipMemsetAsync(out, 0, (size_t)B * N * sizeof(float), st) == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
     }
     const bool mfma_small = B > g_gemv_max_rows && mfma_eligible(L, B, 1, K, N, packed) && workspace != nullptr;
+    if (is_f8(precision) && (B <= g_gemv_max_rows || !mfma_eligible(L, B, 1, K, N, packed)))
+        return FQL_ERR_BAD_PRECISION;                 // fp8 exists on the MFMA path only: no silent float32 fallback
+    if (is_f8(precision) && !mfma_small) return FQL_ERR_WORKSPACE;
     if (B <= 4 && !mfma_small) {
         if ((K % 32 == 0) && aligned16(packed) && aligned16(x) && gemv_lds_bytes(B, K) <= 150 * 1024) {
             switch (B) {
@@ -674,7 +656,6 @@ static int linear_f32_core(const float *x, const uint8_t *packed, const float *s
         }
         return run_generic(x, packed, scales, zps, out, nullptr, nullptr, 1, B, K, N, st, bias);
     }
-    if (is_f8(precision) && !mfma_eligible(L, B, 1, K, N, packed)) return FQL_ERR_ALIGNMENT;   // fp8 exists on the MFMA path only
     if (mfma_eligible(L, B, 1, K, N, packed))
         return run_mfma(L, x, FQL_DTYPE_F32, nullptr, 0, packed, scales, zps, out, FQL_DTYPE_F32, nullptr, nullptr, 1, B, K, N,
                         workspace, workspace_bytes, st, false, is_f8(precision), bias);
@@ -867,7 +848,7 @@ static int group_entry(const float *x, const uint8_t *packed, const float *scale
         default: return launch_gemv<3, true>(x, packed, scales, zps, out, K, N, st, bias, group);
         }
     }
-    if (batch && per <= 128 && K % 256 == 0)                     // few rows per group: 32 x 32 blocks, K split over the waves
+    if (batch && per <= 128 && K % 256 == 0 && (T + 31) / 32 <= 65535)   // few rows per group: 32 x 32 blocks, K split over the waves
         hipLaunchKernelGGL((group_mfma_kernel<true, 1>), dim3((N + 31) / 32, (T + 31) / 32, E), dim3(256), 0, st, x, packed, scales,
                            zps, out, tpe, offs, T, K, N, group, bias);
     else if (batch && (long long)((N + 127) / 128) * ((per + 63) / 64) * groups >= 2LL * compute_units())
@@ -1114,7 +1095,6 @@ static int gemm_i8_entry(int cfg, const int8_t *limbs, const float *delta, const
                          int K, int N, int precision, void *stream, void *scratch, size_t scratch_bytes)
 {
     const int L = limbs_of(precision);
-    const bool product_choice = cfg < 0;                     // the library's own tile choice (else: an explicit tuning id)
     if (L < 0) return FQL_ERR_BAD_PRECISION;
     if (E <= 0 || T < 0 || K <= 0 || N < 0) return FQL_ERR_BAD_SHAPE;
     if (K & 1) return FQL_ERR_ODD_K;
@@ -1149,7 +1129,6 @@ static int gemm_i8_entry(int cfg, const int8_t *limbs, const float *delta, const
         return launch_gemm<1>(cfg, w, packed, scales, zps, out, FQL_DTYPE_F32, tokens_per_expert, input_offsets, E, T, K, Kp, MBT, N, st);
     if (L == 2)
         return launch_gemm<2>(cfg, w, packed, scales, zps, out, FQL_DTYPE_F32, tokens_per_expert, input_offsets, E, T, K, Kp, MBT, N, st);
-    if (product_choice) return launch_product_gemm3(cfg, w, packed, scales, zps, out, FQL_DTYPE_F32, tokens_per_expert, input_offsets, E, T, K, Kp, MBT, N, st);
     return launch_gemm<3>(cfg, w, packed, scales, zps, out, FQL_DTYPE_F32, tokens_per_expert, input_offsets, E, T, K, Kp, MBT, N, st);
 }
 
@@ -1200,7 +1179,6 @@ FQL_API int fql_tune_chosen_cfg(int precision, int E, int T, int K, int N, int g
     if (L < 0) return -1;
     return is_f8(precision) ? choose_cfg_f8(E, T, N, grouped != 0) : choose_cfg(L, E, T, K, N, grouped != 0);
 }
-FQL_API int fql_tune_set_split_small(int on) { const int old = g_split_small; g_split_small = on ? 1 : 0; return old; }
 FQL_API int fql_tune_set_w4(int on) { const int old = g_use_w4; g_use_w4 = on ? 1 : 0; return old; }
 
 

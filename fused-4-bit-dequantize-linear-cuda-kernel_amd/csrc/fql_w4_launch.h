@@ -11,7 +11,6 @@ struct FqlW4Args {
     const int32_t *tpe; const int32_t *offs;
     int E, T, K, Kp, MBT, N;
     int n_tiles, m_slots, n_alt;
-    int part;                // FQL expert_part(): 0 all rows, 1 all but a small last remainder of each expert
     float *scratch; const float *bias;
     long long blocks;
     hipStream_t stream;

@@ -23,6 +23,8 @@ class QuantizedLinear(nn.Module):
         self.out_features = out_features
         self.precision = precision
         # not in the reference (per-row only, python/quantize.py:73-80): per-group scales along K, buffers [N, K / group_size]
+        if group_size is not None and (group_size <= 0 or group_size % 2 != 0 or in_features % group_size != 0):
+            raise ValueError("group_size must be positive, even and divide in_features")
         self.group_size = None if group_size in (None, in_features) else group_size
         # not in the reference (it asserts `bias is None`, python/module.py:84): an optional float32 bias, added in the
         # kernels' epilogues.  Without one the module's state_dict is exactly the reference's three buffers.

@@ -142,13 +142,31 @@ class QuantizedMoE(nn.Module):
         return moe
 
     def _stack(self, device):
-        key = tuple((t.data_ptr(), t._version) for e in self.experts for t in (e.packed_weights, e.scales, e.zero_points))
-        if self._stacked is None or self._stacked[0] != key or self._stacked[1].device != device:
-            packed = torch.stack([e.packed_weights for e in self.experts]).to(device)
-            scales = torch.stack([e.scales for e in self.experts]).to(device)
-            zps = torch.stack([e.zero_points for e in self.experts]).to(device)
-            self._stacked = (key, packed, scales, zps)
-        return self._stacked[1:]
+        """The experts' buffers as ONE [E, N, K/2] / [E, N] / [E, N] set for the grouped launch -- without a second copy of
+        the weights: the stacked tensors become the storage and every expert's registered buffers are re-bound to views
+        of them (state_dict keys, shapes and in-place loads are unchanged; ``.to()`` / a replaced expert break the
+        views, which the next call detects by address and repairs).  Only when the module lives on another device than
+        the inputs is a side copy kept, as before."""
+        names = ("packed_weights", "scales", "zero_points")
+        st = self._stacked
+        if st is not None and st[0].device == device:
+            views = all(getattr(e, n).data_ptr() == st[k][i].data_ptr() for i, e in enumerate(self.experts) for k, n in enumerate(names))
+            if views:                                            # the experts' buffers ARE the stacked storage
+                return st[:3]
+            key = tuple((getattr(e, n).data_ptr(), getattr(e, n)._version) for e in self.experts for n in names)
+            if st[3] == key:                                     # side copy of a module on another device, still current
+                return st[:3]
+        on_device = all(getattr(e, n).device == device for e in self.experts for n in names)
+        stacked = tuple(torch.stack([getattr(e, n) for e in self.experts]).to(device) for n in names)
+        key = None
+        if on_device:
+            for i, e in enumerate(self.experts):
+                for k, n in enumerate(names):
+                    e._buffers[n] = stacked[k][i]               # a view: the per-expert copy is released
+        else:
+            key = tuple((getattr(e, n).data_ptr(), getattr(e, n)._version) for e in self.experts for n in names)
+        self._stacked = stacked + (key,)
+        return stacked
 
     def forward(self, expert_inputs: List[torch.Tensor]) -> List[torch.Tensor]:
         """One tensor ``[m_e, K]`` per expert in, one ``[m_e, N]`` per expert out (in x's dtype;

@@ -121,44 +121,72 @@ def _linear_group_forward(input, packed_weights, scales, zero_points, bias, prec
     for t in (packed_weights, scales, zero_points):
         if t.device != dev:
             raise RuntimeError("all tensors must be on the same device")
+    if packed_weights.dtype != torch.uint8 or scales.dtype != torch.float32 or zero_points.dtype != torch.float32:
+        raise RuntimeError("packed_weights must be uint8, scales and zero_points float32")
     if bias is not None:
         if bias.device != dev or bias.dtype != torch.float32 or bias.numel() != N:
             raise RuntimeError("bias must be a float32 tensor with output_dim elements on the input's device")
         bias = bias.contiguous()
+    # (named: a temporary made by .contiguous() must outlive the launch that reads it)
+    x_c, p_c, s_c, z_c = input.contiguous(), packed_weights.contiguous(), scales.contiguous(), zero_points.contiguous()
     out = torch.empty((B, N), dtype=torch.float32, device=dev)
     prec = _precision(precision)
     with torch.cuda.device(dev):
         L = _native.lib()
         ws, ws_ptr = _workspace(L.fql_group_workspace_bytes(1, B, K, N, group, prec), dev)
-        rc = L.fql_linear_group_ws_fwd_f32(input.data_ptr(), packed_weights.data_ptr(), scales.contiguous().data_ptr(),
-                                           zero_points.contiguous().data_ptr(),
+        rc = L.fql_linear_group_ws_fwd_f32(x_c.data_ptr(), p_c.data_ptr(), s_c.data_ptr(), z_c.data_ptr(),
                                            None if bias is None else bias.data_ptr(), out.data_ptr(), B, K, N,
                                            group, prec, ws_ptr, 0 if ws is None else ws.numel(), _stream_ptr(dev))
     _native.check(rc, "fql_linear_group_ws_fwd_f32")
     return out
 
 
+def _check_group_scales(packed_weights, scales, zero_points, dev, E, N, K):
+    """Per-group constants of a grouped call: CUDA tensors on ``dev``, uint8 / float32, [E, N, K / group_size] with an even
+    group size.  Returns the group size."""
+    for name, t in (("packed_weights", packed_weights), ("scales", scales), ("zero_points", zero_points)):
+        if not t.is_cuda or t.device != dev:
+            raise RuntimeError(f"{name} must be a CUDA tensor on the inputs' device")
+    if packed_weights.dtype != torch.uint8:
+        raise RuntimeError("packed_weights must be uint8")
+    if scales.dtype != torch.float32 or zero_points.dtype != torch.float32:
+        raise RuntimeError("scales and zero_points must be float32")
+    if scales.dim() != 3 or tuple(scales.shape[:2]) != (E, N) or tuple(zero_points.shape) != tuple(scales.shape) \
+            or scales.shape[2] == 0 or K % scales.shape[2] != 0:
+        raise RuntimeError("per-group scales and zero_points must be [E, N, K / group_size]")
+    group = K // scales.shape[2]
+    if group % 2 != 0:
+        raise RuntimeError("group_size must be even")
+    return group
+
+
 def moe_group_forward(packed_weights, scales, zero_points, inputs, tokens_per_expert, input_offsets, precision="default"):
     """Grouped per-expert INT4 GEMM with per-GROUP scales along K: ``scales`` / ``zero_points`` [E, N, K / group_size].
-    Float32 contraction (include/fql_int4.h); rows no expert covers are zero."""
+    Batches of 8+ rows per expert run on the INT8 matrix cores (limb accumulators folded in float32 per group), smaller
+    ones on the float32 matrix-core / FMA kernels (include/fql_int4.h); rows no expert covers are zero."""
     if not inputs.is_cuda or inputs.dtype != torch.float32 or inputs.dim() != 2 or packed_weights.dim() != 3:
         raise RuntimeError("inputs must be a CUDA float32 [T, K] tensor and packed_weights [E, N, K/2]")
     E, N, K2 = packed_weights.shape
     T, K = inputs.shape
-    if K != 2 * K2 or scales.dim() != 3 or tuple(scales.shape[:2]) != (E, N) or tuple(zero_points.shape) != tuple(scales.shape) \
-            or K % scales.shape[2] != 0:
-        raise RuntimeError("per-group scales and zero_points must be [E, N, K / group_size]")
-    group = K // scales.shape[2]
+    if K != 2 * K2:
+        raise RuntimeError("packed_weights dim 2 must be hidden_dim / 2")
     dev = inputs.device
+    group = _check_group_scales(packed_weights, scales, zero_points, dev, E, N, K)
+    for name, t in (("tokens_per_expert", tokens_per_expert), ("input_offsets", input_offsets)):
+        if not t.is_cuda or t.device != dev:
+            raise RuntimeError(f"{name} must be a CUDA tensor on the inputs' device")
+        if t.numel() != E:
+            raise RuntimeError("tokens_per_expert and input_offsets must have num_experts elements")
     tpe = tokens_per_expert.to(device=dev, dtype=torch.int32).contiguous()
     offs = input_offsets.to(device=dev, dtype=torch.int32).contiguous()
+    # (named: a temporary made by .contiguous() must outlive the launch that reads it)
+    x_c, p_c, s_c, z_c = inputs.contiguous(), packed_weights.contiguous(), scales.contiguous(), zero_points.contiguous()
     out = torch.empty((T, N), dtype=torch.float32, device=dev)
     prec = _precision(precision)
     with torch.cuda.device(dev):
         L = _native.lib()
         ws, ws_ptr = _workspace(L.fql_group_workspace_bytes(E, T, K, N, group, prec), dev)
-        rc = L.fql_moe_group_ws_fwd_f32(packed_weights.contiguous().data_ptr(), scales.contiguous().data_ptr(),
-                                        zero_points.contiguous().data_ptr(), inputs.contiguous().data_ptr(),
+        rc = L.fql_moe_group_ws_fwd_f32(p_c.data_ptr(), s_c.data_ptr(), z_c.data_ptr(), x_c.data_ptr(),
                                         tpe.data_ptr(), offs.data_ptr(), out.data_ptr(), E, T, K, N, group, prec,
                                         ws_ptr, 0 if ws is None else ws.numel(), _stream_ptr(dev))
     _native.check(rc, "fql_moe_group_ws_fwd_f32")
@@ -344,8 +372,9 @@ def moe_gather_forward(packed_weights, scales, zero_points, tokens, row_index, t
     out = torch.empty((T, N), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         ws, ws_ptr = _workspace(L.fql_moe_workspace_bytes(E, T, K, N, prec), dev)
-        rc = L.fql_moe_gather_fwd_f32(packed_weights.contiguous().data_ptr(), scales.contiguous().data_ptr(),
-                                      zero_points.contiguous().data_ptr(), tokens.data_ptr(), ri.data_ptr(), n_tokens,
+        packed_weights_c, scales_c, zero_points_c = packed_weights.contiguous(), scales.contiguous(), zero_points.contiguous()   # (named: must outlive the launch)
+        rc = L.fql_moe_gather_fwd_f32(packed_weights_c.data_ptr(), scales_c.data_ptr(),
+                                      zero_points_c.data_ptr(), tokens.data_ptr(), ri.data_ptr(), n_tokens,
                                       tpe.data_ptr(), offs.data_ptr(), out.data_ptr(), E, T, K, N, prec,
                                       ws_ptr, 0 if ws is None else ws.numel(), _stream_ptr(dev))
     _native.check(rc, "fql_moe_gather_fwd_f32")
@@ -375,8 +404,9 @@ def moe_gated_forward(packed_weights, scales, zero_points, gate_up, tokens_per_e
     out = torch.empty((T, N), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         ws, ws_ptr = _workspace(L.fql_moe_workspace_bytes(E, T, K, N, prec), dev)
-        rc = L.fql_moe_gated_fwd_f32(packed_weights.contiguous().data_ptr(), scales.contiguous().data_ptr(),
-                                     zero_points.contiguous().data_ptr(), gate_up.data_ptr(), tpe.data_ptr(),
+        packed_weights_c, scales_c, zero_points_c = packed_weights.contiguous(), scales.contiguous(), zero_points.contiguous()   # (named: must outlive the launch)
+        rc = L.fql_moe_gated_fwd_f32(packed_weights_c.data_ptr(), scales_c.data_ptr(),
+                                     zero_points_c.data_ptr(), gate_up.data_ptr(), tpe.data_ptr(),
                                      offs.data_ptr(), out.data_ptr(), E, T, K, N, prec,
                                      ws_ptr, 0 if ws is None else ws.numel(), _stream_ptr(dev))
     _native.check(rc, "fql_moe_gated_fwd_f32")
@@ -503,8 +533,9 @@ def dequantize_forward(packed_weights, scales, zero_points):
     N, K2 = packed_weights.shape
     w = torch.empty((N, 2 * K2), dtype=torch.float32, device=packed_weights.device)
     with torch.cuda.device(packed_weights.device):
-        rc = _native.lib().fql_dequantize_f32(packed_weights.data_ptr(), scales.contiguous().data_ptr(),
-                                              zero_points.contiguous().data_ptr(), w.data_ptr(), N, 2 * K2,
+        scales_c, zero_points_c = scales.contiguous(), zero_points.contiguous()   # (named: must outlive the launch)
+        rc = _native.lib().fql_dequantize_f32(packed_weights.data_ptr(), scales_c.data_ptr(),
+                                              zero_points_c.data_ptr(), w.data_ptr(), N, 2 * K2,
                                               _stream_ptr(packed_weights.device))
     _native.check(rc, "fql_dequantize_f32")
     return w
@@ -548,11 +579,12 @@ _SCRATCH = {}
 
 
 def gemm_scratch(prec, device):
-    """The residual-pass scratch of phase 2 (one cached buffer per device; contents never outlive a launch)."""
+    """The residual-pass scratch of phase 2: one cached buffer per (device, STREAM) -- its slots are indexed by workgroup and
+    wave only, so two launches that overlap on different streams must not share one; contents never outlive a launch."""
     n = _native.lib().fql_gemm_scratch_bytes(prec)
     if n == 0:
         return None
-    key = (device.index, n)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, n)
     if key not in _SCRATCH:
         _SCRATCH[key] = torch.empty(n, dtype=torch.uint8, device=device)
     return _SCRATCH[key]
@@ -664,8 +696,9 @@ def moe_forward_fp8(packed_weights, scales, zero_points, inputs_e4m3, act_scales
     out = torch.empty((T, N), dtype=out_dtype, device=dev)
     with torch.cuda.device(dev):
         ws, ws_ptr = _workspace(L.fql_moe_workspace_bytes(E, T, K, N, _native.PRECISION_FP8), dev)
-        rc = L.fql_moe_fwd_f8(packed_weights.contiguous().data_ptr(), scales.contiguous().data_ptr(),
-                              zero_points.contiguous().data_ptr(), x8.data_ptr(),
+        packed_weights_c, scales_c, zero_points_c = packed_weights.contiguous(), scales.contiguous(), zero_points.contiguous()   # (named: must outlive the launch)
+        rc = L.fql_moe_fwd_f8(packed_weights_c.data_ptr(), scales_c.data_ptr(),
+                              zero_points_c.data_ptr(), x8.data_ptr(),
                               None if act_scales is None else act_scales.data_ptr(), tpe.data_ptr(), offs.data_ptr(),
                               out.data_ptr(), _DTYPES[out_dtype], E, T, K, N, ws_ptr, 0 if ws is None else ws.numel(),
                               _stream_ptr(dev))
@@ -703,9 +736,10 @@ def linear_forward_fp8(x_e4m3, act_scales, packed_weights, scales, zero_points, 
         return out
     with torch.cuda.device(dev):
         ws, ws_ptr = _workspace(L.fql_linear_workspace_bytes(B, K, N, _native.PRECISION_FP8), dev)
+        packed_weights_c, scales_c, zero_points_c = packed_weights.contiguous(), scales.contiguous(), zero_points.contiguous()   # (named: must outlive the launch)
         rc = L.fql_linear_fwd_f8(x8.data_ptr(), None if act_scales is None else act_scales.data_ptr(),
-                                 packed_weights.contiguous().data_ptr(), scales.contiguous().data_ptr(),
-                                 zero_points.contiguous().data_ptr(), out.data_ptr(), _DTYPES[out_dtype], B, K, N,
+                                 packed_weights_c.data_ptr(), scales_c.data_ptr(),
+                                 zero_points_c.data_ptr(), out.data_ptr(), _DTYPES[out_dtype], B, K, N,
                                  ws_ptr, 0 if ws is None else ws.numel(), _stream_ptr(dev))
     _native.check(rc, "fql_linear_fwd_f8")
     return out

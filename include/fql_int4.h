@@ -77,7 +77,9 @@ extern "C" {
  *                         (v_mfma_scale_f32_32x32x64_f8f6f4, float32 accumulation) -- the "fp8 activations + INT4
  *                         weights" configuration of BASELINE.json configs[4].  ~2.7e-2 relative error on randn
  *                         activations (the format's, not the kernel's): outside the 1e-3 parity claim.  MFMA path
- *                         only (K % 32 == 0, 16-byte aligned weights, more than 2 rows for the linear op). */
+ *                         only: K % 32 == 0, 16-byte aligned weights and, for the linear op, more than 2 rows --
+ *                         otherwise FQL_ERR_BAD_PRECISION (never a silent float32 computation); a NULL / short
+ *                         workspace is FQL_ERR_WORKSPACE. */
 #define FQL_PRECISION_FP8 8
 
 /* Element types of activations and outputs for the dtype-generic entry points (fql_linear_fwd / fql_moe_fwd).
@@ -99,7 +101,8 @@ FQL_API const char *fql_error_string(int code);
  *   scales  [N] float32,  zps [N] float32
  *   out     [B][N] float32, contiguous, fully overwritten
  *   workspace: fql_linear_workspace_bytes(B, K, N, precision) bytes, 16-byte aligned
- *              (0 bytes are needed for B <= 2; B = 3, 4 also run with NULL, on the slower GEMV kernel)
+ *              (0 bytes for B <= 2 in every precision: those shapes run on the float32 GEMV kernel and never touch a
+ *              workspace; B = 3, 4 also run with NULL, on the slower GEMV kernel)
  * Any even K is accepted; K % 32 == 0 with 16-byte aligned `packed` takes the fast paths.
  * ------------------------------------------------------------------------------------- */
 FQL_API size_t fql_linear_workspace_bytes(int B, int K, int N, int precision);
@@ -180,10 +183,11 @@ FQL_API int fql_linear_fwd_f8(const uint8_t *x_e4m3, const float *act_scales, co
  *
  *   scales, zps [N][K / group_size] float32 ([E][N][K / group_size] for the grouped form); group_size even, divides K.
  * Any shape, no workspace.  The weights are dequantised in registers, (q - zp) * scale as the reference kernel does per
- * element, and the contraction is float32: on the float32 matrix-core instruction for 4 or more rows per group with
- * K % 64 == 0, group_size % 32 == 0 and 16-byte aligned bases, one wave per output row (float32 FMA) otherwise.  The
- * integer MFMA kernels need a single scale per output row: per-row quantisation (group_size == K) stays on the faster
- * entry points above.
+ * element, and the contraction is float32: up to 3 rows of ONE matrix (K % 32 == 0, group_size % 32 == 0, 16-byte
+ * aligned bases) on the GEMV kernel with the constants folded per 32-k chunk; 4 or more rows per group (K % 64 == 0,
+ * group_size % 32 == 0, aligned bases) on the float32 matrix-core instruction; one wave per output row (float32 FMA)
+ * otherwise.  The integer MFMA kernels need a single scale per output row: per-row quantisation (group_size == K) stays
+ * on the faster entry points above.
  * ------------------------------------------------------------------------------------- */
 FQL_API int fql_linear_group_fwd_f32(const float *x, const uint8_t *packed, const float *scales,
                                      const float *zps, const float *bias, float *out, int B, int K, int N,

@@ -7,8 +7,11 @@ EXACT_REL_FRO = 2e-6          # ||got - ref64||_F / ||ref64||_F
 # fast mode (2 limbs, 15-bit fixed point): north_star bound is 1e-3 relative; measured ~3e-5.
 FAST_REL_FRO = 2e-4
 # int8 mode (1 limb, 8-bit activations per row): the "8-bit activations + INT4 weights" serving mode of BASELINE
-# config 5; outside the north_star 1e-3 claim, own stated bound (measured ~4e-3 on randn activations).
-INT8_REL_FRO = 2.5e-2
+# config 5; outside the north_star 1e-3 claim, own stated bound: ||d||_F / ||ref||_F < 1.5e-2 at the shapes of
+# test_gpu_parity.py (round-1 bound, kept).  The K = 7168 configs[4] shapes (rows whose maximum sits further out in the
+# tail of 7168 samples: coarser 8-bit quantum against the same rms) and the per-group INT8 kernel get the wider bound.
+INT8_REL_FRO = 1.5e-2
+INT8_REL_FRO_LARGE_K = 2.5e-2
 # GEMV / generic float32 FMA paths: summation-order noise only.
 FMA_REL_FRO = 2e-6
 

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (EXACT_REL_FRO, FAST_REL_FRO, INT8_REL_FRO, FP8_ACC_SCALED_REL_FRO, rel_fro, act_limbs_reference,
+from helpers import (EXACT_REL_FRO, FAST_REL_FRO, INT8_REL_FRO_LARGE_K as INT8_REL_FRO, FP8_ACC_SCALED_REL_FRO, rel_fro, act_limbs_reference,
                      decode_limbs)
 from oracle import oracle as O
 from oracle import c_oracle as C

@@ -121,20 +121,11 @@ def test_w4_headline_shape_bit_identical(fq):
     [128, 129, 192, 193, 64, 65, 1, 0],                      # remainders 0, 1, 64 (split off) and 65 (kept)
     [300, 0, 0, 17, 256, 63, 700, 5],
 ])
-def test_split_launch_equals_single_launch(fq, counts):
-    """Product path for grouped 3-limb calls = the wide launch without each expert's small last remainder + a decode-size
-    launch for those remainders (expert_part(), csrc/fql_common.h).  Every row must carry the bits of the single-launch
-    wide kernel, and the small groups must match the float64 oracle."""
-    from fused_int4_amd import ops, _native
-    lib = _native.lib()
-    old = lib.fql_tune_set_split_small(1)
-    try:
-        _split_case(ops, counts)
-    finally:
-        lib.fql_tune_set_split_small(old)
-
-
-def _split_case(ops, counts):
+def test_short_row_groups_equal_wide_kernel(fq, counts):
+    """Skewed routing: row tiles of at most 64 / 32 rows run with 3 / 2 fragments per wave (csrc/fql_gemm_w4.h, tile classes)
+    and the tiles are walked in cost order.  Every row must carry the bits of the 8-wave wide kernel, through the product
+    entry points too, and the small groups must match the float64 oracle."""
+    from fused_int4_amd import ops
     E, N, K = len(counts), 1100, 1024
     P, S, Z, x, cnt, offs = make_moe(E, N, K, counts, 99 + sum(counts), heavy_every=11)
     T = x.shape[0]
@@ -150,3 +141,32 @@ def _split_case(ops, counts):
     for e, (o, c) in enumerate(zip(offs, cnt)):
         if 0 < c <= 64:
             assert rel_fro(got[o:o + c], ref[o:o + c]) < EXACT_REL_FRO, e
+
+
+def test_quantized_moe_keeps_one_copy_of_the_weights(fq):
+    """QuantizedMoE (benchmark/moe_grouped_gemm/moe_int4_module.py:84-130): the grouped launch needs [E, N, K/2]; the
+    experts' registered buffers become views of that one stacked storage instead of a second copy, state_dict keys and
+    in-place loads keep working, and total_memory_bytes is what the module holds."""
+    torch.manual_seed(0)
+    E, K, N = 4, 256, 384
+    ws = [torch.randn(N, K) * 0.02 for _ in range(E)]
+    moe = fq.QuantizedMoE.from_fp16_weights([w.half() for w in ws]).cuda()
+    keys = sorted(moe.state_dict().keys())
+    xs = [torch.randn(m, K, device="cuda") for m in (5, 0, 70, 33)]
+    out1 = moe(xs)
+    st = moe._stacked[0]
+    for i, e in enumerate(moe.experts):
+        assert e.packed_weights.data_ptr() == st[i].data_ptr()               # a view of the stacked storage
+        assert e.packed_weights.untyped_storage().data_ptr() == st.untyped_storage().data_ptr()
+    assert sorted(moe.state_dict().keys()) == keys
+    held = sum(b.untyped_storage().nbytes() for b in {id(b.untyped_storage()): b for b in moe.buffers()}.values())
+    assert held == moe.total_memory_bytes
+    # in-place load of other weights goes through the views: the next forward uses them, without re-stacking
+    other = fq.QuantizedMoE.from_fp16_weights([(w * 1.5).half() for w in ws]).cuda()
+    moe.load_state_dict(other.state_dict())
+    assert moe._stacked[0].data_ptr() == st.data_ptr()
+    out2 = moe(xs)
+    ref2 = other(xs)
+    for a, b in zip(out2, ref2):
+        assert torch.equal(a, b)
+    assert not torch.equal(out1[2], out2[2])
