@@ -102,22 +102,32 @@ def _timed_passes(fn, threads, budget_s, warm=3, reps=10):
     return ts[len(ts) // 2], ts[0], len(ts)
 
 
+def _host_threads():
+    """Threads for the all-core CPU figure: the cores this process may run on, capped at the pool's CPU share per GPU
+    (16): a 256-thread torch pool on a 16-core share ran the same pass 5x SLOWER than one thread."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("FQL_BENCH_CPU_THREADS", "16"))))
+
+
 def cpu_baseline_moe(P, S, Z, x, tpe, offs, K, N, budget_s=24.0):
     """The oracle (CPU port of the reference's dequantize-then-matmul, python/quantize.py:176-202, applied per expert as
     benchmark/moe_grouped_gemm/moe_int4_module.py:123-125 does) timed on the host cores on a BOUNDED sample of the
     same workload: the first experts of the pass, as many as fit the time budget; all cores and one thread."""
-    from oracle import oracle as O
-    Pn, Sn, Zn, xn = P.cpu().numpy(), S.cpu().numpy(), Z.cpu().numpy(), x.cpu().numpy()
+    from oracle import oracle_torch as OT       # the oracle in the reference's own tensor ops (multi-threaded elementwise + F.linear)
+    Pn, Sn, Zn, xn = P.cpu(), S.cpu(), Z.cpu(), x.cpu()
     tp, of = tpe.cpu().numpy(), offs.cpu().numpy()
     E = Pn.shape[0]
-    cores = os.cpu_count() or 1
+    cores = _host_threads()
 
     def sample(n_exp):
         def run():
             for e in range(n_exp):
                 c, o = int(tp[e]), int(of[e])
                 if c > 0:
-                    O.reference_quantized_linear(xn[o:o + c], Pn[e], Sn[e], Zn[e])
+                    OT.reference_quantized_linear(xn[o:o + c], Pn[e], Sn[e], Zn[e])
         return run
     rows = lambda n_exp: int(sum(int(tp[e]) for e in range(n_exp)))
     torch.set_num_threads(cores)
@@ -134,14 +144,16 @@ def cpu_baseline_moe(P, S, Z, x, tpe, offs, K, N, budget_s=24.0):
                       f"expert; {n_a} timed passes after warm-up, median {med_a*1e3:.1f} ms (min {min_a*1e3:.1f} ms)",
             "one_thread": {"value": val_1, "unit": "TFLOP/s", "cores": 1,
                            "sample": f"first {n_one} expert(s) ({rows(n_one)} rows), {n_1} timed passes, median {med_1*1e3:.1f} ms"},
-            "cpu_model": _cpu_model(), "torch": torch.__version__, "os_cpu_count": cores}
+            "cpu_model": _cpu_model(), "torch": torch.__version__, "os_cpu_count": os.cpu_count()}
 
 
 def cpu_baseline_linear(p, s, z, x, K, N, budget_s=24.0):
-    from oracle import oracle as O
-    pn, sn, zn, xn = p.cpu().numpy(), s.cpu().numpy(), z.cpu().numpy(), x.cpu().numpy()
-    cores = os.cpu_count() or 1
-    run = lambda: O.reference_quantized_linear(xn, pn, sn, zn)
+    from oracle import oracle_torch as OT
+    pn, sn, zn, xn = p.cpu(), s.cpu(), z.cpu(), x.cpu()
+    if xn.dim() == 1:
+        xn = xn[None]
+    cores = _host_threads()
+    run = lambda: OT.reference_quantized_linear(xn, pn, sn, zn)
     med_a, min_a, n_a = _timed_passes(run, cores, budget_s * 0.6)
     med_1, min_1, n_1 = _timed_passes(run, 1, budget_s * 0.4, warm=1, reps=5)
     torch.set_num_threads(cores)
@@ -151,7 +163,7 @@ def cpu_baseline_linear(p, s, z, x, K, N, budget_s=24.0):
                       f"median {med_a*1e3:.1f} ms (min {min_a*1e3:.1f} ms)",
             "one_thread": {"value": fl / med_1 / 1e12, "unit": "TFLOP/s", "cores": 1,
                            "sample": f"{n_1} timed passes, median {med_1*1e3:.1f} ms"},
-            "cpu_model": _cpu_model(), "torch": torch.__version__, "os_cpu_count": cores}
+            "cpu_model": _cpu_model(), "torch": torch.__version__, "os_cpu_count": os.cpu_count()}
 
 
 def check_outputs(out, x, P, S, Z, tpe, offs, prec, rows_per_group=3):

@@ -3,6 +3,7 @@
 // Host-side dispatch only: argument validation, kernel selection, launches on the caller's
 // stream.  No allocation, no synchronisation, no state.
 #include "../../include/fql_int4.h"
+#include "../../include/fql_int4_tune.h"
 #include "fql_common.h"
 #include "fql_act_quant.h"
 #include "fql_act_f8.h"
@@ -180,8 +181,17 @@ constexpr int FQL_NUM_ROWS16_W4 = 4;
     W(0, 3, 6, 8)              /* 3 limbs, full-stage activation ring */ \
     W(1, 3, 6, 4)              /* 3 limbs, 4-step ring */
 constexpr int FQL_NUM_W4 = 2;
-inline bool valid_cfg(int cfg) { return (cfg >= 300 && cfg < 300 + FQL_NUM_W4) || (cfg >= 0 && cfg < FQL_NUM_CFG) || (cfg >= 100 && cfg < 100 + FQL_NUM_ROWS32) ||
-           (cfg >= 200 && cfg < 200 + FQL_NUM_ROWS16) || (cfg >= 220 && cfg < 220 + FQL_NUM_ROWS16_W4);
+// Which wide configurations are BUILT for which limb count: the ones choose_cfg() can return for it, plus the previous
+// headline configuration (0 at 3 limbs: the bit-identity baseline of the tests and A/B tools).  The rest of the list --
+// register budgets of another limb count (up to 1273 spilled registers), tuning experiments that lost -- is not instantiated.
+constexpr bool wide_cfg_built(int L, int id)
+{
+    return L == 3 ? (id == 0 || id == 1 || id == 7 || id == 8 || id == 9 || id == 13)
+         : L == 2 ? (id == 1 || id == 2 || id == 3 || id == 7 || id == 8 || id == 11 || id == 13)
+                  : (id == 1 || id == 2 || id == 7 || id == 8 || id == 11 || id == 12 || id == 13);
+}
+inline bool valid_cfg(int cfg, int L) { return (cfg >= 300 && cfg < 300 + FQL_NUM_W4 && L == 3) || (cfg >= 0 && cfg < FQL_NUM_CFG && wide_cfg_built(L, cfg)) ||
+           (cfg >= 100 && cfg < 100 + FQL_NUM_ROWS32) || (cfg >= 200 && cfg < 200 + FQL_NUM_ROWS16) || (cfg >= 220 && cfg < 220 + FQL_NUM_ROWS16_W4);
 }
 
 // The MFMA path addresses its operands through 32-bit buffer offsets.
@@ -406,8 +416,10 @@ int launch_gemm(int cfg, const Workspace &w, const uint8_t *packed, const float 
 #undef W
 #define X(id, wm, wn, nf, d, bp)                                                                                  \
     case id:                                                                                                      \
-        return launch_gemm_cfg<L, wm, wn, nf, d, bp>(w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, \
-                                                     MBT, N, st);
+        if constexpr (wide_cfg_built(L, id))                                                                      \
+            return launch_gemm_cfg<L, wm, wn, nf, d, bp>(w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, \
+                                                         Kp, MBT, N, st);                                         \
+        else return FQL_ERR_BAD_SHAPE;
         FQL_CFG_LIST(X)
 #undef X
 #define R(i, nf, kg, d, bd, occ)                                                                                   \
@@ -612,7 +624,7 @@ size_t fql_linear_workspace_bytes(int B, int K, int N, int precision)
 {
     (void)N;
     const int L = limbs_of(precision);
-    if (L < 0 || B <= g_gemv_max_rows || B <= 0 || K <= 0 || (K % 32) != 0) return 0;   // (GEMV shapes use no workspace)
+    if (L < 0 || (B <= g_gemv_max_rows && !is_f8(precision)) || B <= 0 || K <= 0 || (K % 32) != 0) return 0;   // (GEMV shapes use no workspace; fql_linear_fwd_f8 takes any B on the MFMA path)
     Workspace w = carve(nullptr, L, B, 1, padded_k(K), has_residual(L, is_f8(precision)));
     return w.bytes;
 }
@@ -1109,7 +1121,7 @@ static int gemm_i8_entry(int cfg, const int8_t *limbs, const float *delta, const
         if (!valid_cfg_f8(cfg)) return FQL_ERR_BAD_SHAPE;
     } else {
         if (cfg < 0) cfg = choose_cfg(L, E, T, K, N, tokens_per_expert != nullptr);
-        if (!valid_cfg(cfg)) return FQL_ERR_BAD_SHAPE;
+        if (!valid_cfg(cfg, L)) return FQL_ERR_BAD_SHAPE;
     }
     Workspace w;
     w.limbs = const_cast<int8_t *>(limbs);
@@ -1141,13 +1153,13 @@ int fql_gemm_i8_f32(const int8_t *limbs, const float *delta, const int32_t *rows
                          K, N, precision, stream, scratch, scratch_bytes);
 }
 
-// Tuning hook (not part of the public header): the same call with an explicit tile configuration id.
+// Tuning hooks (include/fql_int4_tune.h, not part of the drop-in boundary): the same call with an explicit tile configuration id.
 FQL_API int fql_tune_gemm_i8_f32(int cfg, const int8_t *limbs, const float *delta, const int32_t *rowsum,
                                  const uint8_t *packed, const float *scales, const float *zps,
                                  const int32_t *tokens_per_expert, const int32_t *input_offsets, float *out, int E,
                                  int T, int K, int N, int precision, void *stream, void *scratch, size_t scratch_bytes)
 {
-    if (!(precision == FQL_PRECISION_FP8 ? valid_cfg_f8(cfg) : valid_cfg(cfg))) return FQL_ERR_BAD_SHAPE;
+    if (!(precision == FQL_PRECISION_FP8 ? valid_cfg_f8(cfg) : valid_cfg(cfg, limbs_of(precision)))) return FQL_ERR_BAD_SHAPE;
     return gemm_i8_entry(cfg, limbs, delta, rowsum, packed, scales, zps, tokens_per_expert, input_offsets, out, E, T,
                          K, N, precision, stream, scratch, scratch_bytes);
 }
@@ -1169,6 +1181,12 @@ FQL_API int fql_tune_set_group_i8_min_rows(int rows) { const int old = g_group_i
 FQL_API int fql_tune_set_group_i8(int on) { const int old = g_group_i8; g_group_i8 = on ? 1 : 0; return old; }
 FQL_API int fql_tune_set_gemv_max_rows(int rows) { const int old = g_gemv_max_rows; if (rows >= 0 && rows <= 4) g_gemv_max_rows = rows; return old; }
 FQL_API int fql_tune_num_configs(void) { return FQL_NUM_CFG; }
+FQL_API int fql_tune_is_config(int cfg, int precision)
+{
+    const int L = limbs_of(precision);
+    if (L < 0) return 0;
+    return (is_f8(precision) ? valid_cfg_f8(cfg) : valid_cfg(cfg, L)) ? 1 : 0;
+}
 FQL_API int fql_tune_num_rows32_configs(void) { return FQL_NUM_ROWS32; }
 FQL_API int fql_tune_num_rows16_configs(void) { return FQL_NUM_ROWS16; }
 FQL_API int fql_tune_num_w4_configs(void) { return FQL_NUM_W4; }

@@ -19,7 +19,8 @@
  *     caller-allocated; `*_workspace_bytes` says how much scratch a call needs.
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
  *     null stream), performs no host synchronisation, keeps no state between calls and is
- *     re-entrant.  It is safe to capture into a hipGraph.
+ *     re-entrant.  It is safe to capture into a hipGraph.  (The tuning hooks of fql_int4_tune.h, which no product
+ *     path calls, are the one exception: their setters change process-global dispatch thresholds.)
  *   - return value: FQL_OK (0) or a negative FQL_ERR_* code; fql_error_string() describes it.
  *     Nothing is launched when an error is returned.
  *
@@ -101,8 +102,9 @@ FQL_API const char *fql_error_string(int code);
  *   scales  [N] float32,  zps [N] float32
  *   out     [B][N] float32, contiguous, fully overwritten
  *   workspace: fql_linear_workspace_bytes(B, K, N, precision) bytes, 16-byte aligned
- *              (0 bytes for B <= 2 in every precision: those shapes run on the float32 GEMV kernel and never touch a
- *              workspace; B = 3, 4 also run with NULL, on the slower GEMV kernel)
+ *              (0 bytes for B <= 2: those shapes run on the float32 GEMV kernel and never touch a workspace -- except
+ *              with FQL_PRECISION_FP8, where the size is what fql_linear_fwd_f8 needs, which takes any B on the
+ *              matrix cores; B = 3, 4 also run with NULL, on the slower GEMV kernel)
  * Any even K is accepted; K % 32 == 0 with 16-byte aligned `packed` takes the fast paths.
  * ------------------------------------------------------------------------------------- */
 FQL_API size_t fql_linear_workspace_bytes(int B, int K, int N, int precision);

@@ -173,21 +173,24 @@ def test_heavy_tails_every_tile_configuration(fq, prec):
     limbs, delta, rowsum = ops.act_quant(dx, precision=prec, tokens_per_expert=dc, input_offsets=do)
     assert 0 < int((delta[1] != 0).sum()) < T
     outs = {}
-    for cfg in (list(range(lib.fql_tune_num_configs())) + list(range(100, 100 + lib.fql_tune_num_rows32_configs()))
-                + list(range(200, 200 + lib.fql_tune_num_rows16_configs()))
-                + (list(range(300, 300 + lib.fql_tune_num_w4_configs())) if prec == "exact" else [])):
+    cfgs = [c for c in (list(range(lib.fql_tune_num_configs())) + list(range(100, 100 + lib.fql_tune_num_rows32_configs()))
+                        + list(range(200, 200 + lib.fql_tune_num_rows16_configs()))
+                        + list(range(300, 300 + lib.fql_tune_num_w4_configs())))
+            if lib.fql_tune_is_config(c, ops._precision(prec))]      # (not every wide id is built for every limb count)
+    assert len(cfgs) >= 20 and cfgs[0] in (0, 1)
+    for cfg in cfgs:
         out = torch.full((T, Nn), float("nan"), dtype=torch.float32, device="cuda")
         rc = ops.tune_gemm_i8(cfg, limbs, delta, rowsum, dP, dS, dZ, dc, do, out, E, T, Kk, Nn, prec)
         assert rc == 0, (cfg, rc)
         torch.cuda.synchronize()
         outs[cfg] = out.cpu().numpy()
     ref = C.moe_grouped(P, S, Z, x, counts, offs)
-    assert rel_fro(outs[0], ref) < (EXACT_REL_FRO if prec == "exact" else 3e-4)
+    assert rel_fro(outs[cfgs[0]], ref) < (EXACT_REL_FRO if prec == "exact" else 3e-4)
     for cfg, o in outs.items():
-        assert np.array_equal(o, outs[0]), f"configuration {cfg} differs from configuration 0"
+        assert np.array_equal(o, outs[cfgs[0]]), f"configuration {cfg} differs from configuration {cfgs[0]}"
     # the product entry point (pre-pass + GEMM + scratch from the workspace) gives the same bits
     prod = ops.moe_forward(dP, dS, dZ, dx, None, dc, do, precision=prec).cpu().numpy()
-    assert np.array_equal(prod, outs[0])
+    assert np.array_equal(prod, outs[cfgs[0]])
     # 16-bit outputs: rounded once, from the float32 sum of main and residual parts
     o16 = ops.moe_forward_any(dP, dS, dZ, dx, None, dc, do, precision=prec, out_dtype=torch.bfloat16)
     assert torch.equal(o16.cpu(), torch.from_numpy(prod).to(torch.bfloat16))

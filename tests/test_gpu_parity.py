@@ -376,18 +376,21 @@ def test_every_tile_configuration_is_bit_identical(fq, prec, tol):
     dP, dS, dZ, dx, dc, do = dev(P), dev(S), dev(Z), dev(x), dev(cnt), dev(offs)
     limbs, delta, rowsum = ops.act_quant(dx, precision=prec, tokens_per_expert=dc, input_offsets=do)
     outs = {}
-    for cfg in (list(range(lib.fql_tune_num_configs())) + list(range(100, 100 + lib.fql_tune_num_rows32_configs()))
-                + list(range(200, 200 + lib.fql_tune_num_rows16_configs()))
-                + (list(range(300, 300 + lib.fql_tune_num_w4_configs())) if prec == "exact" else [])):
+    cfgs = [c for c in (list(range(lib.fql_tune_num_configs())) + list(range(100, 100 + lib.fql_tune_num_rows32_configs()))
+                        + list(range(200, 200 + lib.fql_tune_num_rows16_configs()))
+                        + list(range(300, 300 + lib.fql_tune_num_w4_configs())))
+            if lib.fql_tune_is_config(c, ops._precision(prec))]      # (not every wide id is built for every limb count)
+    assert len(cfgs) >= 20 and cfgs[0] in (0, 1)
+    for cfg in cfgs:
         out = torch.full((T, N), float("nan"), dtype=torch.float32, device="cuda")
         rc = ops.tune_gemm_i8(cfg, limbs, delta, rowsum, dP, dS, dZ, dc, do, out, E, T, K, N, prec)
         assert rc == 0, (cfg, rc)
         torch.cuda.synchronize()
         outs[cfg] = out.cpu().numpy()
     ref = C.moe_grouped(P, S, Z, x, cnt, offs)
-    assert rel_fro(outs[0], ref) < tol
+    assert rel_fro(outs[cfgs[0]], ref) < tol
     for cfg, o in outs.items():
-        assert np.array_equal(o, outs[0]), f"configuration {cfg} differs from configuration 0"
+        assert np.array_equal(o, outs[cfgs[0]]), f"configuration {cfg} differs from configuration {cfgs[0]}"
 
 
 def test_moe_equals_per_expert_linear_bitwise(fq):

@@ -169,3 +169,20 @@ def test_e4m3_format_is_pinned_to_torch():
     amax = t.abs().amax(dim=1)
     assert np.array_equal(sc, (amax / 448.0).numpy())
     assert np.array_equal(b, (t / (amax / 448.0)[:, None]).to(torch.float8_e4m3fn).view(torch.uint8).numpy())
+
+
+def test_torch_op_oracle_is_pinned_too():
+    """oracle/oracle_torch.py (the form bench.py's cpu_baseline times: the reference's own tensor ops) against the golden
+    vectors and against the numpy restatement."""
+    import torch
+    from oracle import oracle_torch as OT
+    g = load_golden("f1_quant_16x32")
+    d = OT.dequantize_weights(torch.from_numpy(g["packed"]), torch.from_numpy(g["scales"]), torch.from_numpy(g["zero_points"]))
+    assert np.array_equal(d.numpy(), g["dequant"])
+    for name in ("f2_linear_64x128", "f3_linear_256x512_b4"):
+        g = load_golden(name)
+        args = [torch.from_numpy(np.ascontiguousarray(g[k])) for k in ("x", "packed", "scales", "zero_points")]
+        out = OT.reference_quantized_linear(*args).numpy()
+        assert out.shape == g["out"].shape
+        assert np.allclose(out, g["out"], atol=1e-5, rtol=1e-5)
+        assert np.allclose(out, O.reference_quantized_linear(g["x"], g["packed"], g["scales"], g["zero_points"]), atol=1e-5, rtol=1e-5)

@@ -46,7 +46,8 @@ def main():
         alt.restype = ctypes.c_int
         alt.argtypes = tune.argtypes
     ncfg = lib.fql_tune_num_configs()
-    cfgs = [int(c) for c in a.cfgs.split(",")] if a.cfgs else list(range(ncfg))
+    prec_id = {"exact": 3, "fast": 2, "int8": 1, "fp8": 8}[a.precision]
+    cfgs = [int(c) for c in a.cfgs.split(",")] if a.cfgs else [c for c in range(ncfg) if lib.fql_tune_is_config(c, prec_id)]
     base_cfgs = list(cfgs)
     if alt is not None:
         cfgs = cfgs + [1000 + c for c in base_cfgs]
