@@ -236,6 +236,20 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    def all_gather_cat(t):      # [n, ...] of every rank -> [world * n, ...] (rank-major)
+        src = t.contiguous().cpu() if rehearsal else t.contiguous()
+        parts = [torch.empty_like(src) for _ in range(world)]
+        dist.all_gather(parts, src)
+        return torch.cat(parts).to(t.device)
+
+    def all_reduce_sum(t):
+        if rehearsal:
+            h = t.cpu()
+            dist.all_reduce(h)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t)
+
     def all_reduce_max(t):
         if rehearsal:
             h = t.cpu()
@@ -370,6 +384,44 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     total_flops = flops * (world if (a.workload != "moe" and world > 1) else 1)
     value = total_flops / (ms_per_step * 1e-3) / 1e12
+
+    # ------------------------------------------------------------------ expert-parallel parity (outside the timed region)
+    # The first rows of every rank's output must be, bit for bit (top-k <= 2: one addition per output), what ONE GPU's
+    # grouped computation gives for the same tokens: every rank runs the single-GPU grouped call on the sampled rows
+    # that route to ITS experts, the un-weighted rows are summed over the ranks (one contributor per row: exact) and
+    # combined by the same kernel the expert-parallel step uses.  A mismatch aborts the run without a JSON line.
+    if world > 1 and a.workload == "moe":
+        ns = min(8, t_local)
+        EL = E // world
+
+        all_x, all_idx, all_w = all_gather_cat(x[:ns]), all_gather_cat(idx[:ns]), all_gather_cat(wts[:ns])
+        y_ep = eps[0](x, idx, wts)[:ns].contiguous()                       # one more step on weight set 0 (a collective)
+        flat_e = all_idx.reshape(-1).long()
+        mine = torch.nonzero(torch.div(flat_e, EL, rounding_mode="floor") == rank).reshape(-1)
+        rows_unw = torch.zeros((flat_e.numel(), N), dtype=torch.float32, device=dev)
+        if mine.numel():
+            le = (flat_e[mine] - rank * EL)
+            order = torch.argsort(le, stable=True)
+            grouped = all_x.repeat_interleave(a.top_k, 0).index_select(0, mine.index_select(0, order)).contiguous()
+            tpe_l = torch.bincount(le, minlength=EL).to(torch.int32)
+            offs_l = (torch.cumsum(tpe_l, 0) - tpe_l).to(torch.int32)
+            Pl, Sl, Zl = sets[0]
+            y_l = ops.moe_forward(Pl, Sl, Zl, grouped, None, tpe_l, offs_l, precision=prec)
+            rows_unw[mine.index_select(0, order)] = y_l
+        all_reduce_sum(rows_unw)
+        pos = torch.arange(flat_e.numel(), dtype=torch.int32, device=dev)
+        ref = ops.combine(rows_unw, pos, all_w.float())[rank * ns:(rank + 1) * ns]
+        same = bool(torch.equal(ref, y_ep))
+        diff = float((ref - y_ep).abs().max())
+        flags = torch.tensor([0 if same else 1, 0], device=dev, dtype=torch.float64)
+        flags[1] = diff
+        all_reduce_max(flags)
+        extra["parity_vs_single_gpu"] = {"rows_checked_per_rank": ns, "ranks": world, "bit_identical": float(flags[0]) == 0.0,
+                                         "max_abs_diff": float(flags[1]),
+                                         "how": "sampled rows of every rank's expert-parallel output vs the single-GPU grouped call on "
+                                                "the owning rank + the same combine kernel"}
+        if a.top_k <= 2 and not extra["parity_vs_single_gpu"]["bit_identical"]:
+            raise SystemExit(f"expert-parallel output differs from the single-GPU grouped computation: max |d| = {float(flags[1]):.3e}")
 
     # ------------------------------------------------------------------ expert-parallel phases (outside the timed region)
     ep_roofline = None

@@ -51,7 +51,14 @@ class ExpertParallelMoE:
     def __init__(self, num_experts: int, packed_local: Optional[torch.Tensor] = None,
                  scales_local: Optional[torch.Tensor] = None, zps_local: Optional[torch.Tensor] = None,
                  group=None, precision: str = "default",
-                 expert_fn: Optional[Callable] = None, out_features: Optional[int] = None):
+                 expert_fn: Optional[Callable] = None, out_features: Optional[int] = None,
+                 capacity_factor: Optional[float] = None):
+        """``capacity_factor``: None = exact uneven all-to-alls (one small D2H copy of the split sizes per step);
+        a number f >= 1 = FIXED-CAPACITY all-to-alls: every rank sends every peer a block of
+        ``ceil(f * t_local * top_k / world)`` rows (padded), all sizes are known on the host, the counts stay on the
+        device and nothing is read back.  ``f = world`` can never overflow (bit-identical to the exact path);
+        smaller factors drop the rows past a peer's capacity (their contribution is zero) and raise the device-side
+        flag ``overflowed()`` reports."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -67,6 +74,10 @@ class ExpertParallelMoE:
         self.expert_fn = expert_fn
         self.out_features = out_features
         self.last_split = {}
+        if capacity_factor is not None and capacity_factor < 1:
+            raise ValueError("capacity_factor must be >= 1")
+        self.capacity_factor = capacity_factor
+        self._overflow = None           # device-side flag of the fixed-capacity path (accumulates over steps)
         self.record_phases = False      # set True to collect per-phase GPU events of the next device-path steps
         self.phase_events = []          # one list of (name, torch.cuda.Event) per profiled step
 
@@ -151,8 +162,76 @@ class ExpertParallelMoE:
             n += 1
         return {k: v / n for k, v in acc.items()} if n else {}
 
+    def overflowed(self) -> bool:
+        """Fixed-capacity path: did any step so far drop rows (one D2H read, on demand only)?"""
+        return bool(self._overflow.item()) if self._overflow is not None else False
+
+    def _forward_fixed_capacity(self, x, expert_indices, expert_weights):
+        """Dispatch / combine with equal-split all-to-alls (see ``capacity_factor``): no host read-back in the step.
+        Rows keep the order of the exact path inside every (source rank, expert) run, the local grouped GEMM sees the
+        same rows at the same offsets, so with a capacity that cannot overflow the result is the exact path's, bit for
+        bit.  The grouped call gets a row buffer of the worst-case size (world x capacity) and DEVICE-side counts: rows
+        past the counts are never computed."""
+        G, EL = self.world, self.experts_per_rank
+        t, top_k = expert_indices.shape
+        dev = x.device
+        K = x.shape[1]
+        S = t * top_k
+        C = min(S, int(-(-self.capacity_factor * S // G)))                  # rows per peer, a host constant
+        flat_expert = expert_indices.reshape(-1)
+        order = torch.argsort(flat_expert, stable=True)
+        sorted_expert = flat_expert.index_select(0, order)
+        token_of_slot = torch.div(order, top_k, rounding_mode="floor")
+        counts = torch.bincount(flat_expert, minlength=self.num_experts)    # [E] int64, device
+        exp_off = torch.cumsum(counts, 0) - counts                          # first sorted slot of every expert
+        rank_off = exp_off.view(G, EL)[:, 0]                                # ... of every destination rank
+        dest_rank = torch.div(sorted_expert, EL, rounding_mode="floor")
+        pos = torch.arange(S, device=dev) - rank_off.index_select(0, dest_rank)   # position inside the peer's block
+        valid = pos < C
+        over = (~valid).any()
+        self._overflow = over if self._overflow is None else (self._overflow | over)
+        slot = torch.where(valid, dest_rank * C + pos, torch.full_like(pos, G * C))   # dropped rows -> a dummy row
+        send_buf = torch.zeros((G * C + 1, K), dtype=x.dtype, device=dev)
+        send_buf[slot] = x.index_select(0, token_of_slot)
+        # counts after clipping every peer's block at C rows (rows are in expert order inside a block)
+        in_block = (exp_off.view(G, EL) - rank_off[:, None])
+        sent = (torch.clamp(in_block + counts.view(G, EL), max=C) - torch.clamp(in_block, max=C)).reshape(-1)
+        recv_counts = torch.empty(G * EL, dtype=torch.int64, device=dev)
+        dist.all_to_all_single(recv_counts, sent.contiguous(), group=self.group)
+        recv_buf = torch.empty((G * C, K), dtype=x.dtype, device=dev)
+        dist.all_to_all_single(recv_buf, send_buf[:G * C].contiguous(), group=self.group)
+        # received layout: [source rank][C rows, its local experts in order]; the GEMM wants (local expert, source rank)
+        cnt = recv_counts.view(G, EL)
+        src_incl = torch.cumsum(cnt, 1)                                     # [G, EL]
+        p = torch.arange(C, device=dev).expand(G, C).contiguous()
+        e_of = torch.searchsorted(src_incl, p, right=True)                  # local expert of received slot (s, p); EL = padding
+        is_row = e_of < EL
+        e_cl = torch.clamp(e_of, max=EL - 1)
+        within = p - (src_incl - cnt).gather(1, e_cl)
+        exp_major_cnt = cnt.t().contiguous()                                # [EL, G]
+        exp_major_off = (torch.cumsum(exp_major_cnt.reshape(-1), 0) - exp_major_cnt.reshape(-1)).view(EL, G)
+        s_idx = torch.arange(G, device=dev)[:, None].expand(G, C)
+        dest = torch.where(is_row, exp_major_off[e_cl, s_idx] + within, torch.full_like(p, G * C)).reshape(-1)
+        grouped = torch.zeros((G * C + 1, K), dtype=x.dtype, device=dev)
+        grouped[dest] = recv_buf
+        tpe = cnt.sum(0).to(torch.int32)
+        offs = (torch.cumsum(tpe, 0) - tpe).to(torch.int32)
+        y_grouped = self.expert_fn(grouped[:G * C], tpe, offs)              # [G * C, N]; rows past the counts are zero
+        y_pad = torch.cat([y_grouped, y_grouped.new_zeros((1, y_grouped.shape[1]))])
+        y_recv_order = y_pad.index_select(0, dest)
+        y_back = torch.empty_like(y_recv_order)
+        dist.all_to_all_single(y_back, y_recv_order.contiguous(), group=self.group)
+        y_back = torch.cat([y_back, y_back.new_zeros((1, y_back.shape[1]))])
+        y_sorted = y_back.index_select(0, slot)                             # dropped rows read the zero row
+        inverse = torch.empty_like(order)
+        inverse[order] = torch.arange(S, device=dev)
+        y = y_sorted.index_select(0, inverse).view(t, top_k, -1)
+        return (y * expert_weights.unsqueeze(-1).to(y.dtype)).sum(dim=1)
+
     def forward(self, x: torch.Tensor, expert_indices: torch.Tensor, expert_weights: torch.Tensor) -> torch.Tensor:
         """x [t_local, K] float32, expert_indices / expert_weights [t_local, top_k] -> [t_local, N]."""
+        if self.capacity_factor is not None and self.world > 1 and x.shape[0] > 0:
+            return self._forward_fixed_capacity(x, expert_indices, expert_weights)
         if x.is_cuda and self.num_experts <= 128 and x.shape[0] > 0:
             return self._forward_device(x, expert_indices, expert_weights)
         G, EL = self.world, self.experts_per_rank

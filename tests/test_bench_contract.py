@@ -50,3 +50,5 @@ def test_two_rank_rehearsal():
     assert d["config"]["parallelism"] == "ep2"
     assert set(d["ep_phases_ms_max_over_ranks"]) >= {"dispatch_all_to_all", "regroup_and_grouped_gemm", "combine_all_to_all"}
     assert d["roofline"]["frac"] > 0
+    par = d["parity_vs_single_gpu"]                      # every rank's sampled rows == the single-GPU grouped computation
+    assert par["bit_identical"] and par["max_abs_diff"] == 0.0 and par["ranks"] == 2 and par["rows_checked_per_rank"] > 0

@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _make_problem(E, K, N, tokens, top_k, seed):
+def _make_problem(E, K, N, tokens, top_k, seed, unused_expert=None):
     import fused_int4_amd as fq
     g = torch.Generator().manual_seed(seed)
     P, S, Z = [], [], []
@@ -29,6 +29,8 @@ def _make_problem(E, K, N, tokens, top_k, seed):
         P.append(p); S.append(s); Z.append(z)
     x = torch.randn(tokens, K, generator=g)
     logits = torch.randn(tokens, E, generator=g)
+    if unused_expert is not None:
+        logits[:, unused_expert] = -1e9          # nobody routes there: its rank receives zero rows
     w, idx = torch.topk(torch.softmax(logits, -1), top_k, dim=-1)
     w = w / w.sum(-1, keepdim=True)
     return torch.stack(P), torch.stack(S), torch.stack(Z), x, idx, w
@@ -107,3 +109,54 @@ def test_single_rank_path_needs_no_process_group():
     assert torch.allclose(y, _single_process(P, S, Z, x, idx, w), atol=1e-6)
     with pytest.raises(ValueError):
         ExpertParallelMoE(4)           # no weights and no expert_fn
+
+
+def _worker8(rank, world, port, E, K, N, tokens, top_k, seed, ret):
+    """BASELINE configs[3]'s partition: 8 ranks, ONE expert per rank; expert 5 (rank 5) receives no row at all.  The exact
+    path, the fixed-capacity path (no D2H of split sizes) at a capacity that cannot overflow, and the single-process
+    computation must agree -- the two expert-parallel paths bit for bit."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        from fused_int4_amd.ep import ExpertParallelMoE
+        P, S, Z, x, idx, w = _make_problem(E, K, N, tokens, top_k, seed, unused_expert=5)
+        per = tokens // world
+        sl = slice(rank * per, (rank + 1) * per)
+        shard = ExpertParallelMoE.shard
+        fn = _expert_fn_factory(shard(P, rank, world), shard(S, rank, world), shard(Z, rank, world))
+        ep = ExpertParallelMoE(E, expert_fn=fn, out_features=N)
+        xs, ids, ws = x[sl].contiguous(), idx[sl].contiguous(), w[sl].contiguous()
+        y = ep(xs, ids, ws)
+        received = sum(ep.last_split["dispatch_rows_received"])
+        ref = _single_process(P, S, Z, x, idx, w)[sl]
+        ep_cap = ExpertParallelMoE(E, expert_fn=fn, out_features=N, capacity_factor=float(world))
+        y_cap = ep_cap(xs, ids, ws)
+        ep_small = ExpertParallelMoE(E, expert_fn=fn, out_features=N, capacity_factor=1.0)
+        y_small = ep_small(xs, ids, ws)
+        ret[rank] = (float((y - ref).abs().max()), bool(torch.equal(y_cap, y)), received, ep_cap.overflowed(),
+                     ep_small.overflowed(), bool(torch.isfinite(y_small).all()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_one_expert_each_with_an_idle_rank():
+    world, E = 8, 8
+    mp_ctx = mp.get_context("spawn")
+    ret = mp_ctx.Manager().dict()
+    port = _free_port()
+    procs = [mp_ctx.Process(target=_worker8, args=(r, world, port, E, 64, 48, 64, 2, 321, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert len(ret) == world
+    for r in range(world):
+        err, same, received, over_full, over_small, finite = ret[r]
+        assert err < 1e-5, (r, err)
+        assert same, f"rank {r}: fixed-capacity path differs from the exact path"
+        assert not over_full and finite
+        assert (received == 0) == (r == 5), (r, received)
+    assert any(ret[r][4] for r in range(world))          # capacity_factor 1.0 does overflow under uneven routing
