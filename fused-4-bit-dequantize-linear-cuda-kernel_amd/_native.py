@@ -43,6 +43,8 @@ _SYMBOLS = {
                         + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "fql_moe_gather_fwd_f32": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] + [ctypes.c_void_p] * 3
                                + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "fql_moe_gather_scaled_fwd_f32": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] + [ctypes.c_void_p] * 4
+                                      + [ctypes.c_int] * 5 + [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "fql_quantize_rows_f32": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),
     "fql_quantize_tensor_f32": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),
     "fql_unpack_u8": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),

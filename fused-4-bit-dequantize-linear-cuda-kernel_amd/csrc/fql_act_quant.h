@@ -161,9 +161,11 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
     const void *__restrict__ xin, const int32_t *__restrict__ gather, int n_src, float *__restrict__ delta,
     int32_t *__restrict__ rowsum, int8_t *__restrict__ limbs, int T, int K, int KB, int MBT, int rblocks,
     void *__restrict__ out, int out_es, int N, const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
-    int E)
+    int E, const float *__restrict__ row_weight)
 {
-    constexpr int ES = (IN == 0) ? 4 : 2;         // bytes per element of x
+    constexpr int ES = (IN == 0) ? 4 : 2;
+    // row_weight (optional): per grouped row, copied into the plane behind delta's set(s) for the GEMM's epilogue
+    constexpr int DSETS = (L >= 2 && !F8OUT && FQL_RES_ENABLED) ? 2 : 1;         // bytes per element of x
     // AR rows per workgroup: 4 at throughput sizes (measured best at configs[2]); 1 when there are only a few rows in
     // all (decode / small-batch linear), where the pre-pass is a latency chain and a row spread over 256 threads
     // (16 values each) shortens every link of it
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
     if constexpr (F8OUT) {
         // ---- pass 2 (fp8): y = x / scale rounded to e4m3, scale = max|x| / 448 (1 for an all-zero row)
         const float scale = (bad || m == 0.0f) ? 1.0f : m / 448.0f;
-        if (tid < R_ && tok >= 0) delta[tok] = bad ? __builtin_nanf("") : scale;
+        if (tid < R_ && tok >= 0) { delta[tok] = bad ? __builtin_nanf("") : scale; if (row_weight != nullptr) delta[(size_t)DSETS * T + tok] = row_weight[tok]; }
         long long sum8 = 0;
         for (int slab = 0; slab < slabs; ++slab) {
             if (slabs > 1) load_slab(slab);
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
     }
     const int e = act_exponent<L>(bad ? 0.0f : m);
     const float inv = bad ? 0.0f : ldexpf(1.0f, -e);           // non-finite row: limbs 0, delta NaN -> outputs NaN
-    if (tid < R_ && tok >= 0) delta[tok] = bad ? __builtin_nanf("") : ldexpf(1.0f, e);
+    if (tid < R_ && tok >= 0) { delta[tok] = bad ? __builtin_nanf("") : ldexpf(1.0f, e); if (row_weight != nullptr) delta[(size_t)DSETS * T + tok] = row_weight[tok]; }
 
     // ---- pass 2: quantise and store.  Pass 3 (rows flagged as heavy-tailed only, L >= 2): the RESIDUAL of pass 2's
     //      rounding, r = x / delta - X in [-1/2, 1/2] (exact in float32), as a second fixed-point value

@@ -114,7 +114,7 @@ template <int L, int WM, int WN, int NF, int DEPTH, int BDEPTH, bool F8 = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     const int8_t *__restrict__ limbs, const float *__restrict__ delta,
     const int32_t *__restrict__ rowsum, const uint8_t *__restrict__ packed,
-    const float *__restrict__ scales, const float *__restrict__ zps, void *__restrict__ out, int out_kind,
+    const float *__restrict__ scales, const float *__restrict__ zps, void *__restrict__ out, int out_kind_flags,
     const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
     int E, int T, int K, int Kp, int MBT, int N, int n_tiles_min, int m_slots, float *__restrict__ res_scratch,
     const float *__restrict__ bias, int n_tiles_alt)
@@ -122,6 +122,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub
     using C = GemmCfg<L, WM, WN, NF, DEPTH, BDEPTH>;
     constexpr int KS = C::KS, D = C::D;
+    // out_kind_flags: bits 0-1 the output element type (FQL_DTYPE_*), bit 3: multiply every output row by its row weight
+    // (plane delta[sets * T + t], written by the pre-pass of fql_moe_gather_scaled_fwd_f32: the routing weight folded into
+    // the epilogue, so that the combine step is a pure gather-add).  One rounding, after the bias: (x W^T + b) * w.
+    const int out_kind = out_kind_flags & 3;
+    const bool row_scaled = (out_kind_flags & 8) != 0;
     constexpr bool RES = FQL_RES_ENABLED && (L >= 2) && !F8;                    // residual limb set for heavy-tailed rows (see GemmTile)
     static_assert(!F8 || (L == 1 && D % 2 == 0), "the fp8 form has one activation byte plane and consumes k-steps in pairs");
     using acc_t = typename std::conditional<F8, v16f, v16i>::type;
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     const int rl = wm * FQL_MB + l31_e;
     const bool row_ok = active && rl < rows_valid;
     const int t = row_ok ? row0 + rl : 0;
-    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)delta, 0, (RES ? 2 : 1) * T * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)delta, 0, ((RES ? 2 : 1) + 1) * T * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)rowsum, 0, (RES ? 2 : 1) * L * T * 4, 0x00020000);
     const int tsel = rpass ? T : 0;                          // second set of per-row values in the residual pass
     const float d = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, (tsel + t) * 4, 0, 0));
@@ -524,6 +529,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
     // main pass after a residual pass: does THIS row have a residual (delta2 != 0)?
     const int d2bits = RES ? __builtin_amdgcn_raw_buffer_load_b32(rsD, (T + t) * 4, 0, 0) : 0;   // unconditional load
     const bool addp = RES && (d2bits & 0x7fffffff) != 0;
+    const float rw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, row_scaled ? ((RES ? 2 : 1) * T + t) * 4 : OOB, 0, 0));
     __builtin_amdgcn_sched_barrier(0);
     issue_prologue(nxt, tid_e);
     __builtin_amdgcn_sched_barrier(0);
@@ -576,6 +582,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
                         const v4f b4 = *reinterpret_cast<const v4f *>(sz + 2 * C::BN + c0);
 #pragma unroll
                         for (int c = 0; c < 4; ++c) o[c] += b4[c];
+                    }
+                    if (row_scaled) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] *= rw;
                     }
                     store_out4(out, out_kind, (size_t)t * N, n0 + c0, N, vec, o);
                 }

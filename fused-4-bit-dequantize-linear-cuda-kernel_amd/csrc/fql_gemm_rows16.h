@@ -56,13 +56,18 @@ template <int L, int NF, int KG, int BDEPTH, int NWAVES = 8>
 __global__ __launch_bounds__(64 * NWAVES, 2) void gemm_i8_rows16_kernel(
     const int8_t *__restrict__ limbs, const float *__restrict__ delta,
     const int32_t *__restrict__ rowsum, const uint8_t *__restrict__ packed,
-    const float *__restrict__ scales, const float *__restrict__ zps, void *__restrict__ out, int out_kind,
+    const float *__restrict__ scales, const float *__restrict__ zps, void *__restrict__ out, int out_kind_flags,
     const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
     int E, int T, int K, int Kp, int MBT, int N, int n_tiles_min, int m_slots, float *__restrict__ res_scratch,
     const float *__restrict__ bias, int n_tiles_alt)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = Rows16Cfg<L, NF, KG, BDEPTH, NWAVES>;
+    // out_kind_flags: bits 0-1 the output element type (FQL_DTYPE_*), bit 3: multiply every output row by its row weight
+    // (plane delta[sets * T + t], written by the pre-pass of fql_moe_gather_scaled_fwd_f32: the routing weight folded into
+    // the epilogue, so that the combine step is a pure gather-add).  One rounding, after the bias: (x W^T + b) * w.
+    const int out_kind = out_kind_flags & 3;
+    const bool row_scaled = (out_kind_flags & 8) != 0;
     constexpr bool RES = FQL_RES_ENABLED && (L >= 2);                           // residual limb set for heavy-tailed rows (fql_gemm_i8.h)
     constexpr int NG = C::NG, BD = C::BD;
     constexpr int OOB = 0x7fff0000;
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void gemm_i8_rows16_kernel(
     const size_t wbytes = (size_t)N * (size_t)(K >> 1);
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
         (void *)limbs, 0, (int)((size_t)(RES ? 2 : 1) * L * KB * MBT * 8192), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)delta, 0, (RES ? 2 : 1) * T * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)delta, 0, ((RES ? 2 : 1) + 1) * T * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)rowsum, 0, (RES ? 2 : 1) * L * T * 4, 0x00020000);
     const int a_stage = MBT * 8192;
     const int a_limb = KB * MBT * 8192;
@@ -219,6 +224,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void gemm_i8_rows16_kernel(
     v4i afr[2][4][L];                                          // [parity of the stage][64-k step][limb]
     float szr[C::SZN];
     int drow[1 + L];                                           // delta bits and limb row sums of this lane's row
+    int rwbits = 0;                                           // this lane's row weight (row_scaled)
     int d2bits = 0;                                            // delta2 bits of this lane's row (heavy-tailed rows: fql_gemm_i8.h)
     auto issue_weights = [&](const __amdgpu_buffer_rsrc_t rs, int so, int slot, int nfw) {   // pieces past this wave's fragments: no traffic
 #pragma unroll
@@ -260,6 +266,7 @@ const __amdgpu_buffer_rsrc_t rsBi = __builtin_amdgcn_make_buffer_rsrc(
 #pragma unroll
         for (int l = 0; l < L; ++l) drow[1 + l] = __builtin_amdgcn_raw_buffer_load_b32(rsR, (L * tsel + l * T + t) * 4, 0, 0);
         if (RES) d2bits = __builtin_amdgcn_raw_buffer_load_b32(rsD, (T + t) * 4, 0, 0);
+        if (row_scaled) rwbits = __builtin_amdgcn_raw_buffer_load_b32(rsD, ((RES ? 2 : 1) * T + t) * 4, 0, 0);
     };
 
     int ev = 0; (void)ev;
@@ -313,6 +320,7 @@ const __amdgpu_buffer_rsrc_t rsBi = __builtin_amdgcn_make_buffer_rsrc(
     for (int i = 0; i < C::SZN; ++i)
         if (tid + i * C::THREADS < 3 * C::BN) sz[tid + i * C::THREADS] = szr[i];
     const float d = __builtin_bit_cast(float, drow[0]);
+    const float rw = __builtin_bit_cast(float, rwbits);
     const bool addp = RES && (d2bits & 0x7fffffff) != 0;
     float rsum[L];
 #pragma unroll
@@ -464,6 +472,10 @@ const __amdgpu_buffer_rsrc_t rsBi = __builtin_amdgcn_make_buffer_rsrc(
                     const v4f b4 = *reinterpret_cast<const v4f *>(sz + 2 * C::BN + c0);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) o[c] += b4[c];
+                }
+                if (row_scaled) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) o[c] *= rw;
                 }
                 store_out4(out, out_kind, (size_t)t * N, done.n0 + c0, N, vec, o);
             }

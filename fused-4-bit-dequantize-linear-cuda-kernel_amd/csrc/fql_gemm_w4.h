@@ -80,7 +80,7 @@ template <int L, int NF, int DEPTH>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
     const int8_t *__restrict__ limbs, const float *__restrict__ delta,
     const int32_t *__restrict__ rowsum, const uint8_t *__restrict__ packed,
-    const float *__restrict__ scales, const float *__restrict__ zps, void *__restrict__ out, int out_kind,
+    const float *__restrict__ scales, const float *__restrict__ zps, void *__restrict__ out, int out_kind_flags,
     const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
     int E, int T, int K, int Kp, int MBT, int N, int n_tiles_min, int m_slots, float *__restrict__ res_scratch,
     const float *__restrict__ bias, int n_tiles_alt)
@@ -93,6 +93,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
     constexpr int NVF = (L * NF * 16 > 256) ? NF - 256 / (L * 16) : 0;
     constexpr bool RES = FQL_RES_ENABLED && (L >= 2);
     constexpr int OOB = 0x7fff0000;
+    // out_kind_flags: bits 0-1 the output element type, bit 3: multiply every output row by its row weight (fql_gemm_i8.h)
+    const int out_kind = out_kind_flags & 3;
+    const bool row_scaled = (out_kind_flags & 8) != 0;
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x;
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         const int rl = wm * FQL_MB + l31;
         const bool row_ok = active && rl < cur.rows_valid;
         const int t = row_ok ? cur.row0 + rl : 0;
-        const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)delta, 0, (RES ? 2 : 1) * T * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)delta, 0, ((RES ? 2 : 1) + 1) * T * 4, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)rowsum, 0, (RES ? 2 : 1) * L * T * 4, 0x00020000);
         const int tsel = rpass ? T : 0;
         const float d = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, (tsel + t) * 4, 0, 0));
@@ -419,6 +422,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         for (int l = 0; l < L; ++l) rsi[l] = __builtin_amdgcn_raw_buffer_load_b32(rsR, (L * tsel + l * T + t) * 4, 0, 0);
         const int d2bits = RES ? __builtin_amdgcn_raw_buffer_load_b32(rsD, (T + t) * 4, 0, 0) : 0;
         const bool addp = RES && (d2bits & 0x7fffffff) != 0;
+        const float rw = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, row_scaled ? ((RES ? 2 : 1) * T + t) * 4 : OOB, 0, 0));
         issue_sz(nxt);
 
         const __amdgpu_buffer_rsrc_t rsWc = weight_rsrc(cur.e), rsWn = weight_rsrc(nxt.e);
@@ -619,7 +623,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
                 o[c] = (tot * d) * s4[c];
             }
         };
-        const bool fast = mode == 0 && vec && out_kind == 0 && bias == nullptr && cur.n0 + (fbase + nfr_c) * 32 <= N &&
+        const bool fast = mode == 0 && vec && out_kind == 0 && bias == nullptr && !row_scaled && cur.n0 + (fbase + nfr_c) * 32 <= N &&
                           (size_t)T * (size_t)N < ((size_t)1 << 29);      // (32-bit byte offsets into `out`)
         if (row_ok_e && !(W4_ABLATE & 16)) {
             // One fragment (32 columns = 16 outputs of this lane) at a time: all its arithmetic as straight-line code, then
@@ -666,6 +670,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
                                 const v4f b4 = *reinterpret_cast<const v4f *>(sz + 2 * C::BN + c0);
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) o[q][c] += b4[c];
+                            }
+                            if (row_scaled) {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) o[q][c] *= rw;
                             }
                             store_out4(out, out_kind, (size_t)t_e * N, cur.n0 + c0, N, vec, o[q]);
                         }

@@ -86,13 +86,14 @@ inline int compute_units()
 
 inline int compute_units_hint() { const int n = compute_units(); return n < 256 ? 256 : n; }
 
-struct Workspace {
-    int8_t *limbs;
-    float *delta;
-    int32_t *rowsum;
-    float *scratch;          // workgroup-private float32 partials of the residual pass (heavy-tailed rows), or nullptr
-    const float *bias;       // optional per-column bias [N] added to the final outputs (not workspace memory: rides along)
-    size_t bytes;
+struct Workspace {            // (every member has a default: a hand-filled Workspace must not carry garbage pointers into a launch)
+    int8_t *limbs = nullptr;
+    float *delta = nullptr;
+    int32_t *rowsum = nullptr;
+    float *scratch = nullptr;          // workgroup-private float32 partials of the residual pass (heavy-tailed rows), or nullptr
+    const float *bias = nullptr;       // optional per-column bias [N] added to the final outputs (not workspace memory: rides along)
+    const float *row_weight = nullptr; // optional per-row output weight [T] (caller's array: the pre-pass copies it into the plane behind delta)
+    size_t bytes = 0;
 };
 
 // Modes with a residual limb set for heavy-tailed rows (csrc/fql_act_quant.h pass 3, csrc/fql_gemm_i8.h): 2 and 3 limbs.
@@ -108,7 +109,7 @@ inline Workspace carve(void *base, int L, int T, int E, int Kp, bool res)
     Workspace w;
     const int sets = res ? 2 : 1;
     const size_t lb = round16(sets * limb_bytes(L, T, E, Kp));
-    const size_t db = round16((size_t)sets * T * sizeof(float));
+    const size_t db = round16((size_t)(sets + 1) * T * sizeof(float));       // + the row-weight plane (fql_moe_gather_scaled_fwd_f32)
     const size_t rb = round16((size_t)sets * L * T * sizeof(int32_t));
     char *p = static_cast<char *>(base);
     w.limbs = reinterpret_cast<int8_t *>(p);
@@ -116,6 +117,7 @@ inline Workspace carve(void *base, int L, int T, int E, int Kp, bool res)
     w.rowsum = reinterpret_cast<int32_t *>(p + lb + db);
     w.scratch = res ? reinterpret_cast<float *>(p + lb + db + rb) : nullptr;
     w.bias = nullptr;
+    w.row_weight = nullptr;
     w.bytes = lb + db + rb + (res ? res_scratch_bytes() : 0);
     return w;
 }
@@ -224,7 +226,7 @@ int launch_act_quant(const void *x, int in_dtype, const int32_t *gather, int n_s
     const int rblocks = mblocks * (single ? FQL_MB : FQL_MB / ACT_ROWS);
     const int zblocks = (tpe != nullptr && out != nullptr) ? (T + 255) / 256 : 0;
     void (*kern)(const void *, const int32_t *, int, float *, int32_t *, int8_t *, int, int, int, int, int, void *, int,
-                 int, const int32_t *, const int32_t *, int);
+                 int, const int32_t *, const int32_t *, int, const float *);
 #define FQL_ACT_PICK(l, in, gate, f8) \
     (single ? act_fused_kernel<l, true, in, gate, f8, 1> : (vec ? act_fused_kernel<l, true, in, gate, f8> : act_fused_kernel<l, false, in, gate, f8>))
     if (f8out) {
@@ -244,7 +246,7 @@ int launch_act_quant(const void *x, int in_dtype, const int32_t *gather, int n_s
 #undef FQL_ACT_PICK
     (void)hipGetLastError();
     hipLaunchKernelGGL(kern, dim3(rblocks + zblocks), dim3(256), 0, st, x, gather, n_src, w.delta, w.rowsum, w.limbs,
-                       T, K, Kp / FQL_KB, MBT, rblocks, out, dtype_bytes(out_dtype), N, tpe, offs, E);
+                       T, K, Kp / FQL_KB, MBT, rblocks, out, dtype_bytes(out_dtype), N, tpe, offs, E, w.row_weight);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
@@ -322,7 +324,7 @@ int launch_gemm_cfg(const Workspace &w, const uint8_t *packed, const float *scal
     if (blocks <= 0 || blocks > 0x7fffffffLL) return FQL_ERR_BAD_SHAPE;
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, w.limbs, w.delta, w.rowsum,
-                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch, w.bias, n_alt);
+                       packed, scales, zps, out, out_dtype | (w.row_weight != nullptr ? 8 : 0), tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch, w.bias, n_alt);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
@@ -343,7 +345,7 @@ int launch_rows32_cfg(const Workspace &w, const uint8_t *packed, const float *sc
     const int cus = compute_units() * C::WG_PER_CU;          // persistent: WG_PER_CU 8-wave workgroups per CU
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, w.limbs, w.delta, w.rowsum,
-                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch, w.bias);
+                       packed, scales, zps, out, out_dtype | (w.row_weight != nullptr ? 8 : 0), tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch, w.bias);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
@@ -368,7 +370,7 @@ int launch_rows16_cfg(const Workspace &w, const uint8_t *packed, const float *sc
     if (blocks <= 0 || blocks > 0x7fffffffLL) return FQL_ERR_BAD_SHAPE;
     if (blocks > cus) blocks = cus;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::THREADS), C::LDS_BYTES, st, w.limbs, w.delta, w.rowsum,
-                       packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch, w.bias, n_alt);
+                       packed, scales, zps, out, out_dtype | (w.row_weight != nullptr ? 8 : 0), tpe, offs, E, T, K, Kp, MBT, N, n_tiles, m_slots, w.scratch, w.bias, n_alt);
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
@@ -392,7 +394,7 @@ int launch_w4_cfg(int L, int nf, int depth, const Workspace &w, const uint8_t *p
     FqlW4Args a;
     a.limbs = w.limbs; a.delta = w.delta; a.rowsum = w.rowsum;
     a.packed = packed; a.scales = scales; a.zps = zps;
-    a.out = out; a.out_kind = out_dtype;
+    a.out = out; a.out_kind = out_dtype | (w.row_weight != nullptr ? 8 : 0);
     a.tpe = tpe; a.offs = offs;
     a.E = E; a.T = T; a.K = K; a.Kp = Kp; a.MBT = MBT; a.N = N;
     a.n_tiles = n_tiles; a.m_slots = m_slots; a.n_alt = n_alt;
@@ -529,7 +531,7 @@ inline int choose_cfg(int L, int E, int T, int K, int N, bool grouped)
 int run_mfma(int L, const void *x, int in_dtype, const int32_t *gather, int n_src, const uint8_t *packed,
              const float *scales, const float *zps, void *out, int out_dtype, const int32_t *tpe, const int32_t *offs,
              int E, int T, int K, int N, void *workspace, size_t workspace_bytes, hipStream_t st, bool gated = false,
-             bool f8 = false, const float *bias = nullptr)
+             bool f8 = false, const float *bias = nullptr, const float *row_weight = nullptr)
 {
     const int Kp = padded_k(K);
     const int MBT = row_blocks(T, E);
@@ -537,6 +539,7 @@ int run_mfma(int L, const void *x, int in_dtype, const int32_t *gather, int n_sr
     Workspace w = carve(workspace, L, T, E, Kp, has_residual(L, f8));
     if (workspace_bytes < w.bytes) return FQL_ERR_WORKSPACE;
     w.bias = bias;
+    w.row_weight = row_weight;
     void *zero_out = (tpe != nullptr) ? out : nullptr;
     int rc;
     if (f8) {                                                // float rows -> e4m3 with a per-row scale, one fp8 MFMA pass
@@ -692,7 +695,7 @@ int fql_linear_bias_fwd_f32(const float *x, const uint8_t *packed, const float *
 static int moe_entry(const uint8_t *packed, const float *scales, const float *zps, const float *inputs,
                      const int32_t *row_index, int n_src, const int32_t *tokens_per_expert,
                      const int32_t *input_offsets, float *out, int E, int T, int K, int N, int precision,
-                     void *workspace, size_t workspace_bytes, void *stream)
+                     void *workspace, size_t workspace_bytes, void *stream, const float *row_weight = nullptr)
 {
     const int L = limbs_of(precision);
     if (L < 0) return FQL_ERR_BAD_PRECISION;
@@ -708,8 +711,9 @@ static int moe_entry(const uint8_t *packed, const float *scales, const float *zp
     if (E > 65535) return FQL_ERR_BAD_SHAPE;
     if (mfma_eligible(L, T, E, K, N, packed))
         return run_mfma(L, inputs, FQL_DTYPE_F32, row_index, n_src, packed, scales, zps, out, FQL_DTYPE_F32,
-                        tokens_per_expert, input_offsets, E, T, K, N, workspace, workspace_bytes, st, false, is_f8(precision));
-    if (row_index != nullptr || is_f8(precision)) return FQL_ERR_ALIGNMENT;     // the fused gather / fp8 exist on the MFMA path only
+                        tokens_per_expert, input_offsets, E, T, K, N, workspace, workspace_bytes, st, false, is_f8(precision),
+                        nullptr, row_weight);
+    if (row_index != nullptr || is_f8(precision) || row_weight != nullptr) return FQL_ERR_ALIGNMENT;     // the fused gather / row weights / fp8 exist on the MFMA path only
     return run_generic(inputs, packed, scales, zps, out, tokens_per_expert, input_offsets, E, T, K, N, st);
 }
 
@@ -731,6 +735,17 @@ int fql_moe_gather_fwd_f32(const uint8_t *packed, const float *scales, const flo
                      N, precision, workspace, workspace_bytes, stream);
 }
 
+
+int fql_moe_gather_scaled_fwd_f32(const uint8_t *packed, const float *scales, const float *zps, const float *tokens,
+                                  const int32_t *row_index, int n_tokens, const float *row_weight,
+                                  const int32_t *tokens_per_expert, const int32_t *input_offsets, float *out, int E, int T,
+                                  int K, int N, int precision, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!row_index || !row_weight) return FQL_ERR_NULL_POINTER;
+    if (is_f8(precision)) return FQL_ERR_BAD_PRECISION;
+    return moe_entry(packed, scales, zps, tokens, row_index, n_tokens, tokens_per_expert, input_offsets, out, E, T, K,
+                     N, precision, workspace, workspace_bytes, stream, row_weight);
+}
 
 int fql_native_dtype_supported(int rows, int E, int K, int N, int precision, const void *packed, int grouped)
 {
@@ -1000,7 +1015,7 @@ int fql_combine_f32(const float *y, const int32_t *pos_of_slot, const float *wei
 {
     if (T < 0 || top_k <= 0 || N < 0 || R < 0) return FQL_ERR_BAD_SHAPE;
     if (T == 0 || N == 0) return FQL_OK;
-    if (!y || !pos_of_slot || !weights || !out || R == 0) return FQL_ERR_NULL_POINTER;
+    if (!y || !pos_of_slot || !out || R == 0) return FQL_ERR_NULL_POINTER;      // weights == NULL: rows already weighted, pure gather-add
     if (T > 65535) return FQL_ERR_BAD_SHAPE;                 // grid.y
     hipLaunchKernelGGL(combine_kernel, dim3((N + 1023) / 1024, T), dim3(256), 0, static_cast<hipStream_t>(stream), y,
                        pos_of_slot, weights, out, T, top_k, N, R);
@@ -1128,6 +1143,7 @@ static int gemm_i8_entry(int cfg, const int8_t *limbs, const float *delta, const
     w.delta = const_cast<float *>(delta);
     w.rowsum = const_cast<int32_t *>(rowsum);
     w.bias = nullptr;
+    w.row_weight = nullptr;
     w.bytes = 0;
     // without (enough) scratch the residual pass of heavy-tailed rows is skipped: the result is then the plain 8L-1 bit one
     // without (enough) scratch the residual pass of heavy-tailed rows is skipped: the result is then the plain 8L-1 bit one

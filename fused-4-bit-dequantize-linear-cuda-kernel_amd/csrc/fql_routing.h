@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void combine_kernel(
     for (int k = 0; k < top_k; ++k) {
         int p = pos_of_slot[t * top_k + k];
         p = p < 0 ? 0 : (p >= R ? R - 1 : p);
-        const float wk = w[t * top_k + k];
+        const float wk = w != nullptr ? w[t * top_k + k] : 1.0f;     // (x * 1 == x: the gather-add form keeps the bits of pre-weighted rows)
         const float *row = y + (size_t)p * N + n;
         if (vec) {
             const v4f v = *reinterpret_cast<const v4f *>(row);

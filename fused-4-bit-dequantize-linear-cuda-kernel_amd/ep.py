@@ -33,10 +33,11 @@ def _local_grouped_gemm(packed, scales, zps, precision):
         return ops.moe_forward(packed, scales, zps, rows, None, tokens_per_expert, input_offsets,
                                precision=precision)
 
-    def gather_fn(rows, row_index, tokens_per_expert, input_offsets):
-        """Same, grouped row i = rows[row_index[i]]: the regrouping copy is fused into the activation pre-pass."""
+    def gather_fn(rows, row_index, tokens_per_expert, input_offsets, row_weight=None):
+        """Same, grouped row i = rows[row_index[i]]: the regrouping copy is fused into the activation pre-pass;
+        ``row_weight``: the routing weight of every grouped row, applied in the GEMM epilogue."""
         return ops.moe_gather_forward(packed, scales, zps, rows, row_index, tokens_per_expert, input_offsets,
-                                      precision=precision)
+                                      precision=precision, row_weight=row_weight)
     fn.gather = gather_fn
     return fn
 
@@ -77,6 +78,10 @@ class ExpertParallelMoE:
         if capacity_factor is not None and capacity_factor < 1:
             raise ValueError("capacity_factor must be >= 1")
         self.capacity_factor = capacity_factor
+        # single-rank device path: routing weights folded into the GEMM epilogue, combine = pure gather-add (SURVEY 8f N1,
+        # second half).  Same bits as the weighted combine for top_k <= 2 (tests/test_gpu_w4.py); measured delta in
+        # profiles/r03_ab_combine_epilogue.txt.
+        self.fold_weights = False
         self._overflow = None           # device-side flag of the fixed-capacity path (accumulates over steps)
         self.record_phases = False      # set True to collect per-phase GPU events of the next device-path steps
         self.phase_events = []          # one list of (name, torch.cuda.Event) per profiled step
@@ -107,8 +112,14 @@ class ExpertParallelMoE:
         mark("start")
         counts, offsets, token_of_sorted, pos_of_slot = ops.route_plan(expert_indices, self.num_experts)
         fused_gather = hasattr(self.expert_fn, "gather") and K % 32 == 0 and x.dtype == torch.float32
+        folded = False
         if G == 1:
-            if fused_gather:
+            if fused_gather and self.fold_weights and x.shape[0] <= 65535:
+                w_sorted = torch.empty(pos_of_slot.numel(), dtype=torch.float32, device=dev)
+                w_sorted[pos_of_slot.long()] = expert_weights.reshape(-1).to(torch.float32)
+                y_sorted = self.expert_fn.gather(x, token_of_sorted, counts, offsets, row_weight=w_sorted)
+                folded = True
+            elif fused_gather:
                 y_sorted = self.expert_fn.gather(x, token_of_sorted, counts, offsets)
             else:
                 y_sorted = self.expert_fn(x.index_select(0, token_of_sorted.long()), counts, offsets)
@@ -143,7 +154,9 @@ class ExpertParallelMoE:
             self.last_split = {"dispatch_rows_sent": in_splits, "dispatch_rows_received": out_splits}
         if G == 1:
             mark("plan_and_grouped_gemm")
-        if y_sorted.dtype == torch.float32 and x.shape[0] <= 65535:
+        if folded:
+            out = ops.combine(y_sorted, pos_of_slot, None, top_k=top_k)
+        elif y_sorted.dtype == torch.float32 and x.shape[0] <= 65535:
             out = ops.combine(y_sorted, pos_of_slot, expert_weights)
         else:
             y = y_sorted.index_select(0, pos_of_slot.long()).view(x.shape[0], top_k, -1)

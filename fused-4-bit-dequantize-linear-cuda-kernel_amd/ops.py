@@ -343,8 +343,10 @@ def _check_grouped_weights(packed_weights, scales, zero_points, dev, K):
 
 
 def moe_gather_forward(packed_weights, scales, zero_points, tokens, row_index, tokens_per_expert,
-                       input_offsets, precision="default"):
+                       input_offsets, precision="default", row_weight=None):
     """Grouped per-expert INT4 GEMM with the dispatch gather fused in: grouped row t = tokens[row_index[t]].
+    ``row_weight`` [T] float32 (optional): grouped row t of the result is multiplied by row_weight[t] in the GEMM epilogue
+    (the routing weight of its (token, slot) pair), so that ``combine(y, pos, None)`` is a pure gather-add.
 
     ``tokens`` [n_tokens, K] float32 in token order, ``row_index`` [T] int32 (e.g. from
     ``routing.dispatch_indices``).  Returns the grouped outputs [T, N]; un-sort / combine with
@@ -367,16 +369,26 @@ def moe_gather_forward(packed_weights, scales, zero_points, tokens, row_index, t
     tpe = tokens_per_expert.to(device=dev, dtype=torch.int32).contiguous()
     offs = input_offsets.to(device=dev, dtype=torch.int32).contiguous()
     tokens = tokens.contiguous()
+    if row_weight is not None:
+        if not row_weight.is_cuda or row_weight.device != dev or row_weight.numel() != T:
+            raise RuntimeError("row_weight must be a CUDA tensor with one element per grouped row")
+        row_weight = row_weight.to(torch.float32).contiguous()
     L = _native.lib()
     prec = _precision(precision)
     out = torch.empty((T, N), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         ws, ws_ptr = _workspace(L.fql_moe_workspace_bytes(E, T, K, N, prec), dev)
         packed_weights_c, scales_c, zero_points_c = packed_weights.contiguous(), scales.contiguous(), zero_points.contiguous()   # (named: must outlive the launch)
-        rc = L.fql_moe_gather_fwd_f32(packed_weights_c.data_ptr(), scales_c.data_ptr(),
-                                      zero_points_c.data_ptr(), tokens.data_ptr(), ri.data_ptr(), n_tokens,
-                                      tpe.data_ptr(), offs.data_ptr(), out.data_ptr(), E, T, K, N, prec,
-                                      ws_ptr, 0 if ws is None else ws.numel(), _stream_ptr(dev))
+        if row_weight is None:
+            rc = L.fql_moe_gather_fwd_f32(packed_weights_c.data_ptr(), scales_c.data_ptr(),
+                                          zero_points_c.data_ptr(), tokens.data_ptr(), ri.data_ptr(), n_tokens,
+                                          tpe.data_ptr(), offs.data_ptr(), out.data_ptr(), E, T, K, N, prec,
+                                          ws_ptr, 0 if ws is None else ws.numel(), _stream_ptr(dev))
+        else:
+            rc = L.fql_moe_gather_scaled_fwd_f32(packed_weights_c.data_ptr(), scales_c.data_ptr(),
+                                                 zero_points_c.data_ptr(), tokens.data_ptr(), ri.data_ptr(), n_tokens,
+                                                 row_weight.data_ptr(), tpe.data_ptr(), offs.data_ptr(), out.data_ptr(),
+                                                 E, T, K, N, prec, ws_ptr, 0 if ws is None else ws.numel(), _stream_ptr(dev))
     _native.check(rc, "fql_moe_gather_fwd_f32")
     return out
 
@@ -440,10 +452,26 @@ def route_plan(expert_indices, num_experts):
     return counts, offsets, token_of_sorted, pos_of_slot
 
 
-def combine(y, pos_of_slot, expert_weights):
-    """out[t] = sum_k expert_weights[t, k] * y[pos_of_slot[t*top_k + k]] in one launch (routing.py:172-189)."""
+def combine(y, pos_of_slot, expert_weights, top_k=None):
+    """out[t] = sum_k expert_weights[t, k] * y[pos_of_slot[t*top_k + k]] in one launch (routing.py:172-189).
+    ``expert_weights=None`` (with ``top_k``): the rows already carry their weights -- a pure gather-add."""
     if not y.is_cuda or y.dtype != torch.float32 or y.dim() != 2:
         raise RuntimeError("y must be a CUDA float32 [rows, N] tensor")
+    if expert_weights is None:
+        if not top_k:
+            raise RuntimeError("top_k is needed when the rows carry their weights")
+        T = pos_of_slot.numel() // top_k
+        if T > 65535:
+            raise RuntimeError("combine handles up to 65535 tokens per call")
+        dev = y.device
+        y = y.contiguous()
+        pos = pos_of_slot.to(device=dev, dtype=torch.int32).contiguous()
+        out = torch.empty((T, y.shape[1]), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _native.lib().fql_combine_f32(y.data_ptr(), pos.data_ptr(), None, out.data_ptr(), T, top_k,
+                                               y.shape[1], y.shape[0], _stream_ptr(dev))
+        _native.check(rc, "fql_combine_f32")
+        return out
     T, top_k = expert_weights.shape
     if T > 65535:
         raise RuntimeError("combine handles up to 65535 tokens per call")

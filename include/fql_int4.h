@@ -154,6 +154,17 @@ FQL_API int fql_moe_gather_fwd_f32(const uint8_t *packed, const float *scales, c
                                    float *out, int E, int T, int K, int N, int precision,
                                    void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same with the routing weight folded into the GEMM epilogue (second half;
+ * benchmark/moe_grouped_gemm/routing.py:172-189 multiplies after the fact): out[t][:] = row_weight[t] * (grouped result).
+ * row_weight [T] float32, one per GROUPED row (the weight of the (token, slot) pair the row belongs to).  One float32
+ * rounding after the un-weighted result, so fql_combine_f32(..., weights = NULL), a pure gather-add of these rows, gives
+ * bit for bit what fql_combine_f32 with the weights gives on the un-weighted rows (top_k <= 2).  MFMA path only. */
+FQL_API int fql_moe_gather_scaled_fwd_f32(const uint8_t *packed, const float *scales, const float *zps,
+                                  const float *tokens, const int32_t *row_index, int n_tokens, const float *row_weight,
+                                  const int32_t *tokens_per_expert, const int32_t *input_offsets, float *out,
+                                  int E, int T, int K, int N, int precision, void *workspace, size_t workspace_bytes,
+                                  void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Activations that are ALREADY fp8 (OCP e4m3fn bytes, e.g. the output of an upstream fp8 kernel or of
  * torch's .to(torch.float8_e4m3fn)), with an optional float32 scale per row:
@@ -334,7 +345,8 @@ FQL_API int fql_moe_gated_fwd_f32(const uint8_t *packed, const float *scales, co
  *   device: counts[E] and offsets[E] (= tokens_per_expert / input_offsets), token_of_sorted[n_slots] (the
  *   row_index of fql_moe_gather_fwd_f32) and pos_of_slot[n_slots] (where each slot's result row lands).
  * fql_combine_f32: out[t][:] = sum_{k < top_k} weights[t][k] * y[pos_of_slot[t*top_k + k]][:], k ascending;
- *   y is [R, N], out [T, N] (T <= 65535).
+ *   y is [R, N], out [T, N] (T <= 65535).  weights == NULL: a pure gather-add of rows that already carry their
+ *   weight (fql_moe_gather_scaled_fwd_f32).
  * fql_regroup_index_i32 (expert-parallel receive side): recv_counts[G][EL] rows per (source rank, local expert)
  *   in arrival order -> tokens_per_expert[EL], input_offsets[EL], gather[R] (expert-major position -> received
  *   row, the row_index of fql_moe_gather_fwd_f32) and scatter[R] (its inverse); G * EL <= 8192.

@@ -170,3 +170,29 @@ def test_quantized_moe_keeps_one_copy_of_the_weights(fq):
     for a, b in zip(out2, ref2):
         assert torch.equal(a, b)
     assert not torch.equal(out1[2], out2[2])
+
+
+@pytest.mark.parametrize("tokens,E,K,N,top_k", [(512, 8, 1024, 1100, 2), (40, 4, 256, 200, 2), (33, 6, 512, 96, 1)])
+def test_routing_weight_in_the_gemm_epilogue_equals_weighted_combine(fq, tokens, E, K, N, top_k):
+    """SURVEY 8f N1, second half (reference: benchmark/moe_grouped_gemm/routing.py:172-189 multiplies by the routing weight
+    after the expert GEMMs): the weight folded into the GEMM epilogue (fql_moe_gather_scaled_fwd_f32) + a pure gather-add
+    must give the bits of fql_combine_f32 with the weights, for top_k <= 2; every tile class of the big case is hit."""
+    from fused_int4_amd import ops, routing as R
+    from fused_int4_amd.ep import ExpertParallelMoE
+    g = torch.Generator(device="cuda").manual_seed(tokens + N)
+    q = [fq.quantize_weights(torch.randn(N, K, device="cuda", generator=g) * 0.02) for _ in range(E)]
+    P, S, Z = (torch.stack([t[i] for t in q]) for i in range(3))
+    x = torch.randn(tokens, K, device="cuda", generator=g)
+    route = R.simulate_routing(tokens, E, top_k, "skewed", torch.device("cuda"), 7)
+    ep = ExpertParallelMoE(E, P, S, Z)
+    ref = ep(x, route.expert_indices, route.expert_weights)
+    ep.fold_weights = True
+    got = ep(x, route.expert_indices, route.expert_weights)
+    assert torch.equal(got, ref)
+    # and the scaled rows themselves are (un-scaled row) * weight, one float32 rounding
+    counts, offsets, token_of_sorted, pos_of_slot = ops.route_plan(route.expert_indices, E)
+    w_sorted = torch.empty(pos_of_slot.numel(), device="cuda")
+    w_sorted[pos_of_slot.long()] = route.expert_weights.reshape(-1).float()
+    y = ops.moe_gather_forward(P, S, Z, x, token_of_sorted, counts, offsets)
+    yw = ops.moe_gather_forward(P, S, Z, x, token_of_sorted, counts, offsets, row_weight=w_sorted)
+    assert torch.equal(yw, y * w_sorted[:, None])

@@ -25,3 +25,14 @@ def timeit(fn, n=50):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
 print(f"bare grouped call on pre-grouped rows : {timeit(lambda: ops.moe_forward(P, S, Z, xg, None, tpe, offs)):8.1f} us")
 print(f"expert-parallel wrapper, world size 1 : {timeit(lambda: ep(x, route.expert_indices, route.expert_weights)):8.1f} us")
+ref = ep(x, route.expert_indices, route.expert_weights)
+ep.fold_weights = True
+got = ep(x, route.expert_indices, route.expert_weights)
+print(f"... routing weights folded into the GEMM epilogue, combine = gather-add : "
+      f"{timeit(lambda: ep(x, route.expert_indices, route.expert_weights)):8.1f} us   bit-identical={torch.equal(ref, got)}")
+ep.fold_weights = False
+for rep in range(2):
+    print(f"(repeat) weighted combine {timeit(lambda: ep(x, route.expert_indices, route.expert_weights)):8.1f} us", end="   ")
+    ep.fold_weights = True
+    print(f"folded {timeit(lambda: ep(x, route.expert_indices, route.expert_weights)):8.1f} us")
+    ep.fold_weights = False
