@@ -505,7 +505,12 @@ inline int choose_cfg(int L, int E, int T, int K, int N, bool grouped)
     }
     if (m <= 16) return 202;                                 //  16 x 128 decode tiles: every load one stage ahead
     if (m <= 32) return 103;                                 //  32 x 128, K split 4 ways inside the workgroup
-    if (m <= 64) return (L <= 2) ? 11 : 9;                   //  64 x 384 (1 / 2 limbs: full-stage activation ring)
+    if (m <= 64) {                                           //  64 x 384 (1 / 2 limbs: full-stage activation ring) ...
+        // ... 3 limbs: the one-wave-per-SIMD kernel's 33..64-row tile class (two row blocks x two fragment halves per
+        // workgroup): 79.7 vs 89.3 us at 8 x 64 rows (profiles/r03_small_groups.txt); at 32 rows the 32-row kernel stays (67 vs 70)
+        if (L == 3 && g_use_w4 && padded_k(K) >= 2 * FQL_KB) return 301;
+        return (L <= 2) ? 11 : 9;
+    }
     const int mt = groups * ((m + 127) / 128);
     struct Cand { int cfg, bn; };
     // 3 limbs: 128 x 192 with a 2-step A ring (register budget) / 128 x 128; 2 limbs: 4-step ring, + 128 x 256
