@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-2 bench lines for profiles/ (run on the GPU box from the repo root): bash tools/collect_bench.sh
-o=gpurun_out/bench_r02; mkdir -p $o
+# Bench lines for profiles/ (run on the GPU box from the repo root): bash tools/collect_bench.sh [tag]   (default tag r03)
+tag=${1:-r03}; o=gpurun_out/bench_$tag; mkdir -p $o
 run() { name=$1; shift; timeout -k 10 400 python bench.py "$@" 2>/dev/null | grep '^{' > $o/$name.json; python - <<PY
 import json
 try:

@@ -25,7 +25,7 @@ for pdir in sorted(glob.glob(os.path.join(d, "pmc_*"))):
 
 # ---- launch gaps inside a step (kernel-trace timestamps): pre-pass end -> GEMM start, GEMM end -> next pre-pass start
 for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursive=True):
-    rows = [r for r in csv.DictReader(open(f)) if ("gemm_i8" in r.get("Kernel_Name", "") or "act_fused" in r.get("Kernel_Name", "") or "act_f8" in r.get("Kernel_Name", ""))]
+    rows = [r for r in csv.DictReader(open(f)) if ("gemm_i8" in r.get("Kernel_Name", "") or "gemm_w4" in r.get("Kernel_Name", "") or "act_fused" in r.get("Kernel_Name", "") or "act_f8" in r.get("Kernel_Name", ""))]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     g1, g2, ka, kg = [], [], [], []
     for a, b in zip(rows, rows[1:]):
