@@ -673,6 +673,65 @@ def main():
                                            "'vs_headline_step' is filled in below; not the headline"}
         del out_s
 
+    # ------------------------------------------------------------------ side measurements: the weight-streaming shapes
+    # (HBM-bound: the packed weights are read once per step whatever the row count).  decode32: 32 tokens, top-2 -> 8 rows
+    # per expert on the same 8 x (4096 -> 11008) weights; linear1: QuantizedLinear 4096 -> 11008 at batch 1 (configs[0] on
+    # the GPU), walking the experts' matrices of every weight set so that no call finds its weights in a cache.
+    if (a.workload == "moe" and world == 1 and a.routing == "balanced" and prec in ("default", "exact")
+            and not a.no_side_modes and a.tokens != 32):
+        def time_side(fn, n):
+            t_wake = time.perf_counter()
+            while time.perf_counter() - t_wake < 0.05:
+                for _ in range(8):
+                    fn()
+                torch.cuda.synchronize()
+            tf0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - tf0) / n * 1e3
+        rows_d = 32 * a.top_k
+        md = max(1, rows_d // E)
+        tpe_d = torch.full((E,), md, dtype=torch.int32, device=dev)
+        offs_d = torch.arange(E, dtype=torch.int32, device=dev) * md
+        xd = torch.randn(md * E, K, device=dev)
+
+        def step_decode():
+            P, S, Z = sets[step_i[0] % len(sets)]
+            step_i[0] += 1
+            return ops.moe_forward(P, S, Z, xd, None, tpe_d, offs_d, precision=prec)
+        ms_d = time_side(step_decode, max(50, a.steps))
+        out_d = step_decode()
+        torch.cuda.synchronize()
+        Pd, Sd, Zd = sets[(step_i[0] - 1) % len(sets)]
+        chk_d = check_outputs(out_d, xd, Pd, Sd, Zd, tpe_d, offs_d, prec)
+        extra["decode32"] = {"ms_per_step": ms_d, "rows_per_expert": md, "steps": max(50, a.steps),
+                             "hbm_GBps_packed_weights_e2e": weight_bytes / (ms_d * 1e-3) / 1e9,
+                             "hbm_frac_e2e": weight_bytes / (ms_d * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             "max_rel_err": chk_d["max_rel_err"],
+                             "note": "32 tokens, top-2: 8 rows per expert, pre-pass + GEMM; bytes = the packed weights only; not the headline"}
+        del out_d
+        x1l = torch.randn(1, K, device=dev)
+
+        def step_linear1():
+            P, S, Z = sets[(step_i[0] // E) % len(sets)]
+            e = step_i[0] % E
+            step_i[0] += 1
+            return ops.linear_forward(x1l, P[e], S[e], Z[e], precision=prec)
+        ms_l = time_side(step_linear1, max(100, a.steps))
+        out_l = step_linear1()
+        torch.cuda.synchronize()
+        el = (step_i[0] - 1) % E
+        Pl1, Sl1, Zl1 = sets[((step_i[0] - 1) // E) % len(sets)]
+        chk_l = check_outputs(out_l, x1l, Pl1[el], Sl1[el], Zl1[el], None, None, prec)
+        b1 = N * K // 2 + 8 * N + 4 * K
+        extra["linear1"] = {"ms_per_step": ms_l, "steps": max(100, a.steps),
+                            "hbm_GBps": b1 / (ms_l * 1e-3) / 1e9, "hbm_frac": b1 / (ms_l * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                            "max_rel_err": chk_l["max_rel_err"],
+                            "note": "QuantizedLinear 4096 -> 11008 at batch 1 over the experts' matrices in turn (cold weights); "
+                                    "bytes = the reference's model N*K/2 + 8N + 4K (benchmark/run_benchmark.py:222); not the headline"}
+        del out_l
+
     # ------------------------------------------------------------------ output check of the timed call (A12 / VERDICT r1)
     # the same call once more, compared with the oracle on sampled rows of every group; a wrong result fails the run
     if world == 1 and os.environ.get("FQL_BENCH_SKIP_CHECK") != "1":

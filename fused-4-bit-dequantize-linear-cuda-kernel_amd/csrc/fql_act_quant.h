@@ -50,10 +50,16 @@ __device__ __forceinline__ int act_exponent(float m)
     return e;
 }
 
-// ---- single-launch pre-pass.  One 256-thread workgroup owns ACT_ROWS (4) consecutive padded rows end to end:
+// ---- single-launch pre-pass.  One 256-thread workgroup owns ACT_ROWS (4) consecutive GROUPED rows t end to end:
 //      thread t holds row r = t % ACT_ROWS and the 16-float chunks ch = t / ACT_ROWS + ACT_COLS j of that row
 //      (K <= 4096: the workgroup's whole 64 KiB of x sits in registers, read from HBM exactly once, all loads in
-//      flight together).  Row max -> xor-shuffles + 4-wave LDS combine -> delta; then every 16-float chunk
+//      flight together).  The order of the prologue is the point (in-kernel clock stamps, tools/trace_step.py: the
+//      workgroup is a latency chain): the expert table's two loads are issued first, then ALL loads of x, and only
+//      then the table is scanned for the padded row p of each grouped row (p = padded rows of the earlier experts +
+//      t - first row of t's expert) -- the lookup used to sit in front of the loads (1.3 of 7.1 us).  Padding rows
+//      (an expert's rows are padded to a multiple of 32) are never written: a matrix-core output row depends on its
+//      own activation row only, and the GEMM stores valid rows only.
+//      Row max -> DPP rotations inside the 16-lane rows + one LDS combine -> delta; then every 16-float chunk
 //      becomes one 16-byte limb chunk per limb: k = 16 ch of the row IS lane group g / k-step ks of the fragment
 //      layout (see the header comment), and the rows of a workgroup are neighbouring lanes of the fragment, so
 //      each group of ACT_ROWS threads stores ACT_ROWS x 16 contiguous bytes.  No LDS staging of data, no second
@@ -113,7 +119,7 @@ __device__ __forceinline__ void act_zero_uncovered(int block, void *__restrict__
     }
 }
 
-// Token row of each of the workgroup's ACT_ROWS padded rows p0 .. (-1: padding) into s_tok; returns the number of
+// (fql_act_f8.h: workgroups in PADDED-row order)  Token row of each of the workgroup's ACT_ROWS padded rows p0 .. (-1: padding) into s_tok; returns the number of
 // padded rows in use.  The caller synchronises before reading s_tok.
 struct ActLookupShared { int lo[64], cnt[64], pad[64], total; };
 __device__ __forceinline__ int act_token_rows(int p0, int rows, int *s_tok, ActLookupShared &sh,
@@ -152,10 +158,58 @@ __device__ __forceinline__ int act_token_rows(int p0, int rows, int *s_tok, ActL
     return total;
 }
 
+// Padded row p of each of the workgroup's grouped rows t0 .. t0 + rows - 1 into s_p (-1: no expert owns the row, or it is
+// past T).  Wave 0 only; lane i owns expert base + i, (off_raw, cnt_raw) are the first chunk's table entries, loaded by the
+// caller (expert_chunk_load) before its loads of x.  One ballot per row instead of a serial walk over the experts.
+// The caller synchronises before reading s_p.
+__device__ __forceinline__ void act_padded_rows(int t0, int rows, int *s_p, int off_raw, int cnt_raw,
+                                                const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
+                                                int E, int T, int lane)
+{
+    if (lane < rows) s_p[lane] = (tpe == nullptr && t0 + lane < T) ? t0 + lane : -1;
+    if (tpe == nullptr) return;
+    int cp = 0, ct = 0;
+    for (int base = 0; base < E; base += 64) {
+        if (base > 0) expert_chunk_load(tpe, offs, E, base, lane, off_raw, cnt_raw);
+        const ExpertLane xl = expert_chunk_scan(off_raw, cnt_raw, T, FQL_MB, lane, cp, ct);
+        for (int rr = 0; rr < rows; ++rr) {
+            const int t = t0 + rr, rel = t - xl.lo;
+            const unsigned long long hit = __ballot(t < T && rel >= 0 && rel < xl.cnt);
+            if (hit) {                                        // (ranges do not overlap: at most one expert per row)
+                const int src = __ffsll((long long)hit) - 1;
+                const int pv = __shfl(xl.pad_excl + rel, src, 64);
+                if (lane == 0) s_p[rr] = pv;
+            }
+        }
+    }
+}
+
+// Reduction over the lanes of one wave that hold the same row (lanes = r mod R): rotations inside the 16-lane DPP rows
+// (R <= 8: every lane of a row ends with the result of its residue class), leaving one partial per 16-lane row.
+template <int R, typename Op>
+__device__ __forceinline__ int act_row16_reduce(int v, Op op)
+{
+    if (R <= 8) v = op(v, __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false));   // row_ror:8
+    if (R <= 4) v = op(v, __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false));   // row_ror:4
+    if (R <= 2) v = op(v, __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false));   // row_ror:2
+    if (R <= 1) v = op(v, __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false));   // row_ror:1
+    return v;
+}
+
 // F8OUT (L = 1): the row is scaled by 448 / max|x| and rounded to OCP e4m3 (round to nearest even) instead of being
 // split into int8 limbs -- the "fp8 activations" mode (FQL_PRECISION_FP8, BASELINE.json configs[4]).  delta[t] is the
 // float32 quotient max|x| / 448, the stored byte the conversion of the float32 quotient x / delta[t]; rowsum[0][t]
 // holds sum_k of the ROUNDED values as float32 bits (summed exactly as integers in units of 2^-9).
+// Debug builds (-DFQL_TRACE, tools/trace_step.py): thread 0 of the first and the last 8 workgroups stamps the 100 MHz
+// clock at the phase boundaries of the pre-pass.
+#if defined(FQL_TRACE)
+__device__ unsigned long long fql_trace_act[16 * 16];
+#define FQL_ASTAMP(i) do { const int sl_ = (int)blockIdx.x < 8 ? (int)blockIdx.x : ((int)blockIdx.x + 8 >= rblocks && (int)blockIdx.x < rblocks ? 8 + (int)blockIdx.x - (rblocks - 8) : -1); \
+    if (sl_ >= 0 && sl_ < 16 && threadIdx.x == 0) fql_trace_act[sl_ * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FQL_ASTAMP(i) do { } while (0)
+#endif
+
 template <int L, bool VEC, int IN, bool GATE = false, bool F8OUT = false, int AR = ACT_ROWS>
 __global__ __launch_bounds__(256) void act_fused_kernel(
     const void *__restrict__ xin, const int32_t *__restrict__ gather, int n_src, float *__restrict__ delta,
@@ -171,35 +225,36 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
     // (16 values each) shortens every link of it
     constexpr int R_ = AR, COLS_ = 256 / AR, CH_ = 256 / COLS_;
     static_assert(AR == 1 || AR == 2 || AR == 4 || AR == 8, "rows per workgroup");
-    __shared__ int s_tok[R_];
-    __shared__ uint32_t s_max[4][R_];
-    __shared__ int s_sum[4][R_][L];
+    __shared__ int s_p[R_];
+    __shared__ __attribute__((aligned(16))) uint32_t s_max[R_][16];     // [row][wave * 4 + 16-lane row of the wave]
+    __shared__ __attribute__((aligned(16))) int s_sum[R_][L][16];
     __shared__ long long s_sum8[4][R_];
-    __shared__ float s_ssq[4][R_];
+    __shared__ __attribute__((aligned(16))) float s_ssq[R_][16];
     __shared__ int s_flag[R_];
-    __shared__ ActLookupShared s_lookup;
     static_assert(!F8OUT || L == 1, "fp8 activations are one byte plane");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    FQL_ASTAMP(0);
 
     if ((int)blockIdx.x >= rblocks) {             // ---- coverage workgroups: 256 rows of `out` each
         act_zero_uncovered((int)blockIdx.x - rblocks, out, out_es, N, tpe, offs, E, T);
         return;
     }
 
-    // ---- token row of each of the workgroup's padded rows (-1: padding); total = padded rows in use
-    const int p0 = blockIdx.x * R_;
-    const int total = act_token_rows(p0, R_, s_tok, s_lookup, tpe, offs, E, T);
-    if (p0 >= total) return;                      // past the last expert's rows (uniform per workgroup)
-    __syncthreads();
-
+    // ---- this workgroup's grouped rows t0 .. t0 + R_ - 1 (the last workgroup may hold rows past T: they re-read row
+    //      T - 1 and store nothing)
+    const int t0 = blockIdx.x * R_;
+    if (t0 >= T) return;
     const int r = tid & (R_ - 1), col = tid / R_;   // row of the workgroup, chunk column
-    const int tok = s_tok[r];
-    const int p = p0 + r, mb = p >> 5, r32 = p & 31;
+    const int trow = t0 + r;
+    // the expert table's first 64 entries: loaded now, scanned when the loads of x are on their way
+    int off_raw = 0, cnt_raw = 0;
+    if (tpe != nullptr && wave == 0) expert_chunk_load(tpe, offs, E, 0, lane, off_raw, cnt_raw);
     static_assert(!GATE || IN == 0, "the gated pre-pass takes float32 rows");
     const char *xr = reinterpret_cast<const char *>(xin) +
-                     (size_t)(tok >= 0 ? source_row(gather, n_src, tok) : 0) * K * ES * (GATE ? 2 : 1);
+                     (size_t)source_row(gather, n_src, trow < T ? trow : T - 1) * K * ES * (GATE ? 2 : 1);
     const int nch = KB * 16;                      // 16-float chunks per padded row
     const int slabs = (nch + COLS_ * CH_ - 1) / (COLS_ * CH_);
+    int tok = trow < T ? trow : -1;               // (-1 once the lookup finds no expert for the row either)
 
     // VEC (K % 16 == 0, x 16-byte aligned; host-checked): every load is unconditional.  A chunk past K (the
     // zero padding up to a multiple of 256) or a padding row re-reads valid data -- duplicates do not move the
@@ -252,11 +307,18 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
         }
     };
 
+    // ---- all loads of the first slab, then the padded row of every grouped row (wave 0; the others go on to the maximum)
+    load_slab(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave == 0) act_padded_rows(t0, R_, s_p, off_raw, cnt_raw, tpe, offs, E, T, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    FQL_ASTAMP(1);
+
     // ---- pass 1: row maximum, on the bit patterns: |x| as an unsigned integer orders finite < Inf < NaN, so one
     //      integer max finds the magnitude and flags a non-finite row
     uint32_t mu = 0u;
     for (int slab = 0; slab < slabs; ++slab) {
-        load_slab(slab);
+        if (slab > 0) load_slab(slab);
 #pragma unroll
         for (int j = 0; j < CH_; ++j)
 #pragma unroll
@@ -267,20 +329,25 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
                     mu = u > mu ? u : mu;
                 }
     }
-#pragma unroll
-    for (int o = R_; o < 64; o <<= 1) {
-        const uint32_t n = (uint32_t)__shfl_xor((int)mu, o, 64);
-        mu = n > mu ? n : mu;
-    }
-    if (lane < R_) s_max[wave][lane] = mu;
+    mu = (uint32_t)act_row16_reduce<R_>((int)mu, [](int a, int b) { return (int)((uint32_t)a > (uint32_t)b ? (uint32_t)a : (uint32_t)b); });
+    if ((lane & 15) < R_) s_max[lane & 15][wave * 4 + (lane >> 4)] = mu;
     __syncthreads();
     {
-        const uint32_t a = s_max[0][r] > s_max[1][r] ? s_max[0][r] : s_max[1][r];
-        const uint32_t b = s_max[2][r] > s_max[3][r] ? s_max[2][r] : s_max[3][r];
-        mu = a > b ? a : b;
+        mu = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const v4i q = reinterpret_cast<const v4i *>(s_max[r])[i];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mu = (uint32_t)q[c] > mu ? (uint32_t)q[c] : mu;
+        }
     }
+    // (the same barrier published the lookup)
+    const int p = s_p[r];
+    tok = p >= 0 ? tok : -1;
+    const int mb = p >> 5, r32 = p & 31;
     const bool bad = mu >= 0x7F800000u;
     const float m = __uint_as_float(mu);
+    FQL_ASTAMP(2);
     if constexpr (F8OUT) {
         // ---- pass 2 (fp8): y = x / scale rounded to e4m3, scale = max|x| / 448 (1 for an all-zero row)
         const float scale = (bad || m == 0.0f) ? 1.0f : m / 448.0f;
@@ -313,7 +380,7 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
                 const int kb = ch >> 4, c16 = ch & 15;
                 const int ks = 2 * (c16 >> 2) + (c16 & 1), g = (c16 >> 1) & 1;
                 int8_t *dst = limbs + (((size_t)kb) * MBT + mb) * 8192 + ((ks * 64) + g * 32 + r32) * 16;
-                *reinterpret_cast<v4i *>(dst) = v4i{(int)w0, (int)w1, (int)w2, (int)w3};
+                if (tok >= 0) *reinterpret_cast<v4i *>(dst) = v4i{(int)w0, (int)w1, (int)w2, (int)w3};
             }
         }
 #pragma unroll
@@ -352,19 +419,23 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
                 if (ch >= nch) continue;
                 // All L balanced digits of X at once: Y = X + sum_{l<L-1} 128*256^l has plain base-256 digits
                 // d_l + 128 in its low bytes and the top digit above them, so byte l of Z = Y ^ 0x..8080 is limb l.
+                // (the conversion of bytes l < L-1 from d_l + 128 to two's complement, the XOR, is done on the transposed
+                //  dwords below: 4 bytes at a time)
                 constexpr int BIAS = (L == 3) ? 0x8080 : (L == 2) ? 0x80 : 0;
-                const uint32_t keep = chunk_ok(slab, j) ? 0xFFFFFFFFu : 0u;   // padding: +0.0f whatever was re-read
+                // padding (a chunk past K, re-read data): scaled by zero -> digits 0 whatever was read (the rows are
+                // finite here: a non-finite row has inv = 0 as a whole, and NaN converts to 0)
+                const float inv_c = chunk_ok(slab, j) ? inv : 0.0f;
                 uint32_t Z[16];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float xq = __uint_as_float(__float_as_uint(xv[j][q][i]) & keep) * inv;
+                        const float xq = xv[j][q][i] * inv_c;
                         const float xr = rintf(xq);
                         int v;
                         if (RESID) v = (int)rintf((xq - xr) * (float)(1 << RBITS));
                         else { v = (int)xr; ssq = fmaf(xq, xq, ssq); }
-                        Z[4 * q + i] = (uint32_t)(v + BIAS) ^ (uint32_t)BIAS;
+                        Z[4 * q + i] = (uint32_t)(v + BIAS);
                     }
                 // byte transpose into the limb dwords; inside an 8-group the byte order is (0,2,4,6,1,3,5,7):
                 // dword 2h = k (0,2,4,6) of 8-group h, dword 2h+1 = k (1,3,5,7)
@@ -375,8 +446,8 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
                     const uint32_t za = Z[kbase], zb = Z[kbase + 2], zc = Z[kbase + 4], zd = Z[kbase + 6];
                     const uint32_t lo_ab = __builtin_amdgcn_perm(zb, za, 0x05010400u);      // a0 b0 a1 b1
                     const uint32_t lo_cd = __builtin_amdgcn_perm(zd, zc, 0x05010400u);
-                    w[0][dw] = __builtin_amdgcn_perm(lo_cd, lo_ab, 0x05040100u);            // a0 b0 c0 d0
-                    if (L > 1) w[1 % L][dw] = __builtin_amdgcn_perm(lo_cd, lo_ab, 0x07060302u);   // a1 b1 c1 d1
+                    w[0][dw] = __builtin_amdgcn_perm(lo_cd, lo_ab, 0x05040100u) ^ (L > 1 ? 0x80808080u : 0u);   // a0 b0 c0 d0
+                    if (L > 1) w[1 % L][dw] = __builtin_amdgcn_perm(lo_cd, lo_ab, 0x07060302u) ^ (L > 2 ? 0x80808080u : 0u);   // a1 b1 c1 d1
                     if (L > 2) {
                         const uint32_t hi_ab = __builtin_amdgcn_perm(zb, za, 0x07030602u);  // a2 b2 a3 b3
                         const uint32_t hi_cd = __builtin_amdgcn_perm(zd, zc, 0x07030602u);
@@ -390,7 +461,7 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
 #pragma unroll
                     for (int i = 0; i < 4; ++i) sums[l] = __builtin_amdgcn_sdot4((int)w[l][i], 0x01010101, sums[l], false);
                     int8_t *dst = base + (((size_t)l * KB + kb) * MBT + mb) * 8192 + ((ks * 64) + g * 32 + r32) * 16;
-                    if (store) {
+                    if (store && tok >= 0) {
                         if (FQL_LIMB_WT) store16_wt(dst, v4i{(int)w[l][0], (int)w[l][1], (int)w[l][2], (int)w[l][3]});
                         else *reinterpret_cast<v4i *>(dst) = v4i{(int)w[l][0], (int)w[l][1], (int)w[l][2], (int)w[l][3]};
                     }
@@ -401,31 +472,43 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
     auto reduce_sums = [&](int (&sums)[L]) {
 #pragma unroll
         for (int l = 0; l < L; ++l) {
-#pragma unroll
-            for (int o = R_; o < 64; o <<= 1) sums[l] += __shfl_xor(sums[l], o, 64);
-            if (lane < R_) s_sum[wave][lane][l] = sums[l];
+            sums[l] = act_row16_reduce<R_>(sums[l], [](int a, int b) { return a + b; });
+            if ((lane & 15) < R_) s_sum[lane & 15][l][wave * 4 + (lane >> 4)] = sums[l];
         }
+    };
+    auto total_sum = [&](int row, int l) -> int {              // (fixed order: the result does not depend on timing)
+        int tot = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const v4i q = reinterpret_cast<const v4i *>(s_sum[row][l])[i];
+            tot += (q[0] + q[1]) + (q[2] + q[3]);
+        }
+        return tot;
     };
     int sums[L];
 #pragma unroll
     for (int l = 0; l < L; ++l) sums[l] = 0;
     float ssq = 0.0f;
     emit(std::false_type{}, sums, ssq, true);
+    FQL_ASTAMP(3);
     reduce_sums(sums);
     if (RES) {
-#pragma unroll
-        for (int o = R_; o < 64; o <<= 1) ssq += __shfl_xor(ssq, o, 64);
-        if (lane < R_) s_ssq[wave][lane] = ssq;
+        ssq = __int_as_float(act_row16_reduce<R_>(__float_as_int(ssq), [](int a, int b) { return __float_as_int(__int_as_float(a) + __int_as_float(b)); }));
+        if ((lane & 15) < R_) s_ssq[lane & 15][wave * 4 + (lane >> 4)] = ssq;
     }
     __syncthreads();
     if (tid < R_) {
         int flag = 0;
         if (tok >= 0) {
 #pragma unroll
-            for (int l = 0; l < L; ++l)
-                rowsum[(size_t)l * T + tok] = (s_sum[0][tid][l] + s_sum[1][tid][l]) + (s_sum[2][tid][l] + s_sum[3][tid][l]);
+            for (int l = 0; l < L; ++l) rowsum[(size_t)l * T + tok] = total_sum(tid, l);
             if (RES) {
-                const float tot = (s_ssq[0][tid] + s_ssq[1][tid]) + (s_ssq[2][tid] + s_ssq[3][tid]);   // ||x / delta||^2
+                float tot = 0.0f;                                                      // ||x / delta||^2
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const v4f q = reinterpret_cast<const v4f *>(s_ssq[tid])[i];
+                    tot += (q[0] + q[1]) + (q[2] + q[3]);
+                }
                 const float lim = (float)K * (L == 3 ? 8.3333e10f : 1.3333e6f);                    // K / (12 P^2)
                 flag = (!bad && m != 0.0f && tot < lim && e - RBITS >= -126) ? 1 : 0;
                 delta[(size_t)T + tok] = flag ? ldexpf(1.0f, e - RBITS) : 0.0f;
@@ -433,13 +516,14 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
         }
         if (RES) s_flag[tid] = flag;
     }
+    FQL_ASTAMP(4);
     if (!RES) return;
     __syncthreads();
     {
         int any = 0;
 #pragma unroll
         for (int i = 0; i < R_; ++i) any |= s_flag[i];
-        if (any == 0) return;
+        if (any == 0) { FQL_ASTAMP(5); return; }
     }
 #pragma unroll
     for (int l = 0; l < L; ++l) sums[l] = 0;
@@ -448,7 +532,6 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
     __syncthreads();
     if (tid < R_ && tok >= 0 && s_flag[tid]) {
 #pragma unroll
-        for (int l = 0; l < L; ++l)
-            rowsum[(size_t)(L + l) * T + tok] = (s_sum[0][tid][l] + s_sum[1][tid][l]) + (s_sum[2][tid][l] + s_sum[3][tid][l]);
+        for (int l = 0; l < L; ++l) rowsum[(size_t)(L + l) * T + tok] = total_sum(tid, l);
     }
 }

@@ -161,7 +161,33 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane)
 }
 
 // Processes experts [base, base + 64); carry_pad / carry_tile are the totals of the experts before `base`
-// and are advanced to include this chunk.
+// and are advanced to include this chunk.  In two halves, so that a caller can put other loads between the table's loads
+// and their first use: expert_chunk_load issues them (raw offset / count of this lane's expert, 0 / 0 past E).
+__device__ __forceinline__ void expert_chunk_load(const int32_t *tpe, const int32_t *offs, int E, int base, int lane, int &off_raw, int &cnt_raw)
+{
+    off_raw = 0; cnt_raw = 0;
+    if (base + lane < E) { off_raw = offs[base + lane]; cnt_raw = tpe[base + lane]; }
+}
+__device__ __forceinline__ ExpertLane expert_chunk_scan(int off_raw, int cnt_raw, int T, int bm, int lane, int &carry_pad, int &carry_tile)
+{
+    ExpertLane r;
+    {
+        long long a = off_raw, b = a + (long long)cnt_raw;   // (the clipping of expert_range)
+        a = a < 0 ? 0 : a;
+        b = b > T ? T : b;
+        r.lo = (int)a;
+        r.cnt = b > a ? (int)(b - a) : 0;
+    }
+    const int pad = (r.cnt + FQL_MB - 1) / FQL_MB * FQL_MB;
+    r.tiles = (r.cnt + bm - 1) / bm;
+    const int pad_incl = wave_incl_scan(pad, lane);
+    const int tile_incl = wave_incl_scan(r.tiles, lane);
+    r.pad_excl = carry_pad + pad_incl - pad;
+    r.tile_excl = carry_tile + tile_incl - r.tiles;
+    carry_pad += __shfl(pad_incl, 63, 64);
+    carry_tile += __shfl(tile_incl, 63, 64);
+    return r;
+}
 __device__ __forceinline__ ExpertLane expert_chunk(const int32_t *tpe, const int32_t *offs, int E, int T, int bm,
                                                    int base, int lane, int &carry_pad, int &carry_tile)
 {

@@ -66,12 +66,15 @@ struct W4Cfg {
 
 // Timing experiments only (wrong results), bit mask: 1 no weight park / staging loads, 2 no activation ring refills,
 // 4 no weight-fragment reads, 8 no branch around the last fragment (always all NF), 16 no epilogue arithmetic / stores
+#ifndef W4_SHORT_RING
+#define W4_SHORT_RING 1
+#endif
 #ifndef W4_ABLATE
 #define W4_ABLATE 0
 #endif
 #if defined(FQL_TRACE)
 __device__ unsigned long long fql_trace_w4[8 * 64];
-#define FQL_W4STAMP(i, real) do { if (blockIdx.x < 8 && threadIdx.x == 0 && (i) < 64) fql_trace_w4[blockIdx.x * 64 + (i)] = (real) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
+#define FQL_W4STAMP(i, real) do { const int i_ = (i); if (blockIdx.x < 8 && threadIdx.x == 0 && i_ < 64) fql_trace_w4[blockIdx.x * 64 + i_] = (real) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define FQL_W4STAMP(i, real) do { } while (0)
 #endif
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, g = lane >> 5;
+    FQL_W4STAMP(56, 1);                                      // (trace builds: kernel entry, 100 MHz clock)
     // ---- what a wave does in a tile depends on the tile's rows (short row groups: skewed routing, the tail of a group):
     //        > 64 rows: wave w owns row block w and all NF fragments                      (18 matrix instructions per k-step)
     //      33..64 rows: wave w owns row block w & 1 and fragments 3 (w >> 1) .. + 2          (9)
@@ -155,9 +159,15 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         return r;
     };
     int MB = m_slots, MC2 = 0, MC1 = 0;                      // row tiles per cost group
+    // (the first 64 experts' scan is kept for the prologue's tile table: one load round trip and four wave scans less on
+    //  the way to the first weight load; later table refills scan again, so nothing of it stays live in the matrix loop)
+    RowGroups rg0 = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int cp0 = 0, cb0 = 0, c20 = 0, c10 = 0;
     if (tpe != nullptr) {
         int cp = 0, cb = 0, c2 = 0, c1 = 0;
-        for (int base = 0; base < E; base += 64) (void)row_groups(base, cp, cb, c2, c1);
+        rg0 = row_groups(0, cp, cb, c2, c1);
+        cp0 = cp; cb0 = cb; c20 = c2; c10 = c1;
+        for (int base = 64; base < E; base += 64) (void)row_groups(base, cp, cb, c2, c1);
         MB = __builtin_amdgcn_readfirstlane(cb); MC2 = __builtin_amdgcn_readfirstlane(c2); MC1 = __builtin_amdgcn_readfirstlane(c1);
         if (MB + MC2 + MC1 > m_slots) {                      // overlapping ranges: stay inside the plan
             MB = MB < m_slots ? MB : m_slots;
@@ -191,6 +201,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
     const int n_big = MB * n_tiles, n_c2 = MC2 * n_tiles, n_c1 = MC1 * n_tiles;
     n_real = __builtin_amdgcn_readfirstlane(n_big + n_c2 + n_c1);
     if ((int)blockIdx.x >= n_real) return;
+    FQL_W4STAMP(57, 1);                                      // (row groups counted)
     const int f_base = n_frag / n_tiles, f_rem = n_frag - f_base * n_tiles;
 
     // slots [lo, lo + cnt) of the walk order -> tile ids [lo, lo + cnt), the slots of one XCD (slot & 7: blocks b and b + 8
@@ -204,7 +215,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         return lo + basex + (upto(vb, x) - upto(lo, x));
     };
 
-    auto tile_params = [&](int vb) -> GemmTile {
+    auto tile_params = [&](int vb, auto cached_tag) -> GemmTile {
+        constexpr bool CACHED = decltype(cached_tag)::value;
         GemmTile tp = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (vb >= n_real) return tp;
         const int grp = vb < n_big ? 0 : (vb < n_big + n_c2 ? 1 : 2);
@@ -219,9 +231,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
             tp.rows_valid = T - tp.row0;
             tp.ok = 1;
         } else {
-            int cp = 0, cb = 0, c2 = 0, c1 = 0;
+            int cp = CACHED ? cp0 : 0, cb = CACHED ? cb0 : 0, c2 = CACHED ? c20 : 0, c1 = CACHED ? c10 : 0;
             for (int base = 0; base < E && !tp.ok; base += 64) {
-                const RowGroups x = row_groups(base, cp, cb, c2, c1);
+                const RowGroups x = (CACHED && base == 0) ? rg0 : row_groups(base, cp, cb, c2, c1);
                 const bool mine = grp == 0 ? (ms >= x.big_excl && ms < x.big_excl + x.nbig)
                                            : (grp == 1 ? (x.c2 && ms == x.c2_excl) : (x.c1 && ms == x.c1_excl));
                 const unsigned long long hit = __ballot(mine);
@@ -246,19 +258,45 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
     // ---- the tiles this workgroup will visit, NTAB at a time, described in LDS: {e, row0, prow0, rows_valid, n0, nfr,
     //      ok, has-heavy-tailed-rows}.  Wave w fills entries w, w + 4, ...; later reads are LDS broadcasts.
     int *tab = reinterpret_cast<int *>(lds + 2 * C::W_STAGE + C::SZ_BYTES);
-    auto fill_table = [&](int first) {
+    // (probe = false: the heavy-tail probe of the entries is left to probe_table -- the kernel prologue issues the first
+    //  tile's weight loads between the two, so that the probe's round trip to memory runs under theirs)
+    auto fill_table = [&](int first, auto in_loop_tag) {
+        constexpr bool probe = decltype(in_loop_tag)::value;   // (the prologue's call: cached scan, probe deferred)
         for (int i = wave; i < C::NTAB; i += C::NW) {
             const long long vbl = (long long)blockIdx.x + (long long)(first + i) * (long long)gridDim.x;
-            GemmTile tp = tile_params(vbl < (long long)n_real ? (int)vbl : n_real);
+            GemmTile tp = tile_params(vbl < (long long)n_real ? (int)vbl : n_real, std::integral_constant<bool, !probe>{});
             int hr = 0;
             if constexpr (RES) {
-                if (res_scratch != nullptr && tp.ok) hr = tile_has_residual(delta, T, tp, C::BM, lane);
+                if (probe && res_scratch != nullptr && tp.ok) hr = tile_has_residual(delta, T, tp, C::BM, lane);
             }
             if (lane == 0) {
                 int *p = tab + i * C::TAB_INTS;
                 p[0] = tp.e; p[1] = tp.row0; p[2] = tp.prow0; p[3] = tp.rows_valid;
                 p[4] = tp.n0; p[5] = tp.nfr; p[6] = tp.ok | (vbl < (long long)n_real ? 2 : 0); p[7] = hr;
             }
+        }
+        __syncthreads();
+    };
+    // the probe in two halves: `issue` its loads for this wave's entries, `finish` evaluates them and completes the table.
+    // (vector loads complete in order: issued BEFORE the first weight loads, the probe waits for nothing but itself)
+    constexpr int NPR = C::NTAB / C::NW;
+    ResidualProbe prb[NPR];
+    auto probe_issue = [&]() {
+#pragma unroll
+        for (int j = 0; j < NPR; ++j) {
+            const int *p = tab + (wave + j * C::NW) * C::TAB_INTS;
+            GemmTile tp = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            tp.row0 = __builtin_amdgcn_readfirstlane(p[1]);
+            tp.rows_valid = __builtin_amdgcn_readfirstlane(p[3]);
+            tp.ok = __builtin_amdgcn_readfirstlane(p[6]) & 1;
+            prb[j] = residual_probe_issue(delta, T, tp, C::BM, lane, RES && res_scratch != nullptr);
+        }
+    };
+    auto probe_finish = [&]() {
+#pragma unroll
+        for (int j = 0; j < NPR; ++j) {
+            const int hr = residual_probe_eval(prb[j]);
+            if (lane == 0) tab[(wave + j * C::NW) * C::TAB_INTS + 7] = hr;
         }
         __syncthreads();
     };
@@ -301,7 +339,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
     float *szbuf = reinterpret_cast<float *>(lds + 2 * C::W_STAGE);
 
     v4i bst[NF];                                             // one packed weight stage in flight (global -> VGPR)
-    v4i afr[D][L];                                           // activation ring: D k-steps ahead (8: one full stage)
+    // activation ring.  Tiles with more than 64 rows (288 accumulator registers) keep D k-steps in flight in slots
+    // 0 .. D-1; the short tile classes have the registers for a FULL stage (slot = k-step, 7 steps ahead): vector loads
+    // complete in order, so a weight piece from HBM has to land before the activation fragment issued after it is used --
+    // D - 1 k-steps later.  On a short tile a k-step is 6 or 9 matrix instructions: 3 of them (~0.3 us) are less than the
+    // memory latency, and every stage stalled for the difference.  Between visits the contract stays "k-steps 0 .. D-2 of
+    // the first stage in slots 0 .. D-2": a short visit ramps up in its first stage and down in its last.
+    v4i afr[D][L];
     v4i wf[NF];                                              // weight fragments of the coming k-step
     float szr[C::SZN];
 
@@ -367,17 +411,22 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
     // ---- kernel prologue: the state every visit starts from
     //        LDS buffer fs & 1 holds stage 0 of the visit, bst its stage 1 (in flight), afr the A fragments of its
     //        stage 0 (in flight), wf the weight fragments of its k-step 0, sz[parity] its scale / zero-point slice
-    fill_table(0);
+    fill_table(0, std::false_type{});
+    FQL_W4STAMP(58, 1);                                      // (tile table in LDS)
     int ti = 0;                                              // tile index of this workgroup (table slot ti % NTAB)
     GemmTile cur = load_tile(0);
-    if constexpr (!RES) cur.rp = 0;
     int fs = 0;                                              // stages since kernel start: LDS buffer parity
     int parity = 0;
     {
         const __amdgpu_buffer_rsrc_t rs = weight_rsrc(cur.e);
         const int sW = w_base(cur);
+        // which limb set the first visit reads depends on the heavy-tail probe: its round trip runs under the weights'
+        probe_issue();
         issue_weights(rs, sW, cur.nfr);
         issue_sz(cur);
+        probe_finish();
+        cur = load_tile(0);
+        if constexpr (!RES) cur.rp = 0;
         const int sA = a_base(cur);
 #pragma unroll
         for (int s = 0; s < D; ++s)
@@ -391,6 +440,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         __syncthreads();
         read_first_frags(lds, wave_fbase(tile_class(cur)));
     }
+    FQL_W4STAMP(59, 1);                                      // (first stage parked, second in flight)
 
     int ev = 0; (void)ev;
     for (;;) {                                               // one iteration per VISIT (tile, pass)
@@ -404,7 +454,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         if (rpass) { nxt = cur; nxt.rp = 0; nxt.ad = 1; }
         else {
             ++ti;
-            if ((ti % C::NTAB) == 0) fill_table(ti);         // (rare: more than 16 tiles per workgroup; drains the pipeline)
+            if ((ti % C::NTAB) == 0) fill_table(ti, std::true_type{});         // (rare: more than 16 tiles per workgroup; drains the pipeline)
             nxt = load_tile(ti % C::NTAB);
             if constexpr (!RES) nxt.rp = 0;
         }
@@ -438,6 +488,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         const int nfr_k = cur.nfr;
         v16i acc[L][NACT - NVA > 0 ? NACT - NVA : 1];
         v16i accv[L][NVA > 0 ? NVA : 1];
+        v4i afx[KS - D > 0 ? KS - D : 1][L];                 // ring slots D .. KS-1 of a short visit (never live between visits)
+        auto ring = [&](int slot, int l) -> v4i & { return slot < D ? afr[slot][l] : afx[slot - D][l]; };
 
         // ---- one 256-k stage.  FIRST: the accumulators start from the instruction's zero operand.
         auto stage = [&](auto first_tag, int kt) {
@@ -458,11 +510,15 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
             // scalar offsets of the activation refills, resolved once per stage (out of bounds stays out of bounds when a
             // step offset is added): a single wave has ~6 issue slots per matrix instruction, and a select + add per
             // load and step spent them
-            int sAq[2][L];
+            int sAq[3][L];
+            constexpr int RD = (NACT == NF || W4_SHORT_RING == 0 || (W4_SHORT_RING == 2 && NACT != 2) || (W4_SHORT_RING == 3 && NACT != 3)) ? D : KS;        // ring depth of this tile class
+            const bool last_stage = kt == KT - 1;
 #pragma unroll
             for (int l = 0; l < L; ++l) {
                 sAq[0][l] = sA0 == OOB ? OOB : sA0 + l * a_limb;
                 sAq[1][l] = sA1 == OOB ? OOB : sA1 + l * a_limb;
+                // the next stage's k-steps D .. : not fetched ahead of a visit boundary (ramp down to the contract)
+                sAq[2][l] = (RD > D && last_stage) ? OOB : sAq[1][l];
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -490,9 +546,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
                 auto mm = [&](int j, int l) {                // one matrix instruction of fragment j < NF - NVF
                     if (FIRST && ks == 0) {
                         const v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                        acc[l][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[j], afr[ks % D][l], z, 0, 0, 0);
+                        acc[l][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[j], ring(ks % RD, l), z, 0, 0, 0);
                     } else {
-                        acc[l][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[j], afr[ks % D][l], acc[l][j], 0, 0, 0);
+                        acc[l][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[j], ring(ks % RD, l), acc[l][j], 0, 0, 0);
                     }
                 };
                 auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
@@ -500,8 +556,21 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
                     // the ring slot the PREVIOUS step consumed gets the k-step D - 1 ahead of this one (of this stage, or of
                     // the one after it)
                     if (W4_ABLATE & 2) return;
-                    const int pk = (ks + KS - 1) % KS, tk = ks - 1 + D, w = tk < KS ? 0 : 1;
-                    afr[pk % D][l] = __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff0, sAq[w][l] + (tk % KS) * 1024, 0);
+                    const int pk = (ks + KS - 1) % KS, tk = ks - 1 + RD, w = tk < KS ? 0 : ((tk % KS) >= D ? 2 : 1);
+                    ring(pk % RD, l) = __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff0, sAq[w][l] + (tk % KS) * 1024, 0);
+                };
+                // first stage of a short visit: the ring holds k-steps 0 .. D-2 (the contract between visits: a D-deep visit
+                // fetches k-step D-1 of its first stage in its first step, and so leaves slot D-1 to its successor); fetch
+                // this stage's k-steps D-1 .. KS-2 on top of the regular refills (k-step KS-1 is step 0's regular refill)
+                auto ramp_up = [&]() {
+                    if constexpr (FIRST && RD > D) {
+                        if (W4_ABLATE & 2) return;
+#pragma unroll
+                        for (int tk = (ks == 0 ? D - 1 : D + 2 * ks); tk < D + 2 * ks + 2 && tk < KS - 1; ++tk)
+#pragma unroll
+                            for (int l = 0; l < L; ++l)
+                                ring(tk, l) = __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff0, sAq[0][l] + tk * 1024, 0);
+                    }
                 };
                 auto frag = [&](const char *base, int j) { if (!(W4_ABLATE & 4)) wf[j] = *reinterpret_cast<const v4i *>(base + j * 8192); };
                 auto unpack = [&](int i) {
@@ -555,6 +624,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
                     mm(2, 1); fence(); unpack(2); unpack(3); fence();
                     mm(2, 2); fence(); park0(); fence();
                     park1();
+                    ramp_up();
                 } else {                                     // <= 32 rows: 6 matrix instructions
                     static_assert(NACT == 2, "tile classes: 6, 3 or 2 fragments per wave");
                     mm(0, 0); fence(); frag(fc, 1); fence();
@@ -565,6 +635,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
                     mm(1, 1); fence(); refill(2); unpack(0); fence();
                     mm(1, 2); fence(); unpack(1); unpack(2); fence();
                     unpack(3); park0(); park1();
+                    ramp_up();
                 }
                 if (park) bst[ks % NF] = __builtin_amdgcn_raw_buffer_load_b128(rsW2, voffW, ks < nfr2 ? sW2 + ks * pieceW : OOB, 0);   // (OOB + i * pieceW stays out of bounds)
                 if (ks == NF && kt == KT - 1) park_sz(szbuf + (parity ^ 1) * 3 * C::BN);
@@ -579,7 +650,6 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         stage(T_{}, 0);
         for (int kt = 1; kt < KT; ++kt) stage(F_{}, kt);
         FQL_W4STAMP(ev++, 0);
-        read_first_frags(lds + (fs & 1) * C::W_STAGE, wave_fbase(tile_class(nxt)));   // (lands under the epilogue)
 
         // ---- epilogue: identical arithmetic to gemm_i8_kernel (the weights are the matrix instruction's A operand, so a
         //      lane owns ONE output row t and registers 4q..4q+3 are 4 consecutive output columns)
@@ -682,6 +752,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        // (after the epilogue, not under it: 16 registers held across the epilogue's 200+ live ones were spilled)
+        read_first_frags(lds + (fs & 1) * C::W_STAGE, wave_fbase(tile_class(nxt)));
         };   // visit_body
         // (one copy of K loop + epilogue per tile class, each with its own accumulators: a fragment skipped under a branch
         //  inside ONE copy turns the accumulators into phi nodes and the compiler then spills whole tuples around the epilogue)

@@ -70,9 +70,11 @@ inline bool ensure_lds_attr(PerDeviceFlag &flag, const void *kern, int bytes)
     }
     return true;
 }
+int g_cu_cap = 0;              // tuning hook (tests): pretend the device has this many compute units (multiple of 8; 0 = real count)
 inline int compute_units()
 {
     static int cached[FQL_MAX_DEVICES] = {};
+    if (g_cu_cap > 0) return g_cu_cap;
     const int dev = current_device();
     if (cached[dev] == 0) {
         int n = 0;
@@ -216,14 +218,14 @@ int launch_act_quant(const void *x, int in_dtype, const int32_t *gather, int n_s
                      int Kp, int MBT, void *out, int out_dtype, int N, const int32_t *tpe, const int32_t *offs, int E,
                      hipStream_t st, bool gated = false, bool f8out = false)
 {
-    // 8-row workgroups over the padded rows that can hold real rows (every expert's rows rounded up to 32), plus
-    // (MoE entry point) the workgroups that zero the rows of `out` no expert covers
-    const int mblocks = (tpe == nullptr) ? (T + FQL_MB - 1) / FQL_MB : (T + FQL_MB * E) / FQL_MB;
+    // ACT_ROWS-row workgroups over the grouped rows (each finds its rows' padded positions itself), plus (MoE entry
+    // point) the workgroups that zero the rows of `out` no expert covers
+    const int mblocks = (tpe == nullptr) ? (T + FQL_MB - 1) / FQL_MB : (T + FQL_MB * E) / FQL_MB;   // (upper bound of the padded row blocks)
     const bool vec = (K % 16 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
     // few rows in all (at most two single-row workgroups per CU; measured: 16 rows 6.3 -> 4.6 us, 1280 padded rows 12.5 -> 16.5 us): one row per workgroup -- the pre-pass is a latency
     // chain there and a row spread over 256 threads shortens every link of it (fql_act_quant.h)
     const bool single = vec && mblocks * FQL_MB <= g_act_single_rows;
-    const int rblocks = mblocks * (single ? FQL_MB : FQL_MB / ACT_ROWS);
+    const int rblocks = single ? T : (T + ACT_ROWS - 1) / ACT_ROWS;
     const int zblocks = (tpe != nullptr && out != nullptr) ? (T + 255) / 256 : 0;
     void (*kern)(const void *, const int32_t *, int, float *, int32_t *, int8_t *, int, int, int, int, int, void *, int,
                  int, const int32_t *, const int32_t *, int, const float *);
@@ -1186,6 +1188,10 @@ FQL_API int fql_tune_gemm_i8_f32(int cfg, const int8_t *limbs, const float *delt
 }
 
 #if defined(FQL_TRACE)
+FQL_API int fql_debug_trace_act(unsigned long long *dst)
+{
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(fql_trace_act), sizeof(unsigned long long) * 16 * 16) == hipSuccess ? 0 : -1;
+}
 FQL_API int fql_debug_trace_wide(unsigned long long *dst)
 {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(fql_trace_wide), sizeof(unsigned long long) * 8 * 64) == hipSuccess ? 0 : -1;
@@ -1218,6 +1224,7 @@ FQL_API int fql_tune_chosen_cfg(int precision, int E, int T, int K, int N, int g
     if (L < 0) return -1;
     return is_f8(precision) ? choose_cfg_f8(E, T, N, grouped != 0) : choose_cfg(L, E, T, K, N, grouped != 0);
 }
+FQL_API int fql_tune_set_compute_units(int n) { const int old = g_cu_cap; g_cu_cap = n > 0 ? (n < 8 ? 8 : n - n % 8) : 0; return old; }
 FQL_API int fql_tune_set_w4(int on) { const int old = g_use_w4; g_use_w4 = on ? 1 : 0; return old; }
 
 

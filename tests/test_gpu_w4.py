@@ -196,3 +196,33 @@ def test_routing_weight_in_the_gemm_epilogue_equals_weighted_combine(fq, tokens,
     y = ops.moe_gather_forward(P, S, Z, x, token_of_sorted, counts, offsets)
     yw = ops.moe_gather_forward(P, S, Z, x, token_of_sorted, counts, offsets, row_weight=w_sorted)
     assert torch.equal(yw, y * w_sorted[:, None])
+
+
+@pytest.mark.parametrize("counts,heavy", [
+    ([200, 3, 40, 0, 129, 64, 33, 7, 1, 130], 0),           # every class after every other one in a workgroup's walk
+    ([60, 150, 20, 140, 10, 50], 7),                        # the same with heavy-tailed rows (residual passes in between)
+])
+def test_visit_sequences_of_mixed_tile_classes(fq, counts, heavy):
+    """A workgroup that walks MANY tiles of mixed row counts: the prefetch rings run across the visit boundaries
+    (csrc/fql_gemm_w4.h: the short tile classes keep a full stage of activation fragments in flight, the 128-row class D
+    k-steps, and hand over in a fixed state), so every order of classes must leave every row with the wide kernel's bits.
+    The persistent grid is shrunk to 8 workgroups (tuning hook) to get those walks on a small shape."""
+    from fused_int4_amd import ops, _native
+    lib = _native.lib()
+    E, N, K = len(counts), 1500, 1536
+    P, S, Z, x, cnt, offs = make_moe(E, N, K, counts, 7 + sum(counts), heavy_every=heavy)
+    T = x.shape[0]
+    dP, dS, dZ, dx, dc, do = dev(P), dev(S), dev(Z), dev(x), dev(cnt), dev(offs)
+    limbs, delta, rowsum = ops.act_quant(dx, precision="exact", tokens_per_expert=dc, input_offsets=do)
+    ref_out = run_cfgs(ops, [0], limbs, delta, rowsum, dP, dS, dZ, dc, do, E, T, K, N)[0]
+    for cus in (8, 16, 24):
+        old = lib.fql_tune_set_compute_units(cus)
+        try:
+            outs = run_cfgs(ops, w4_ids(), limbs, delta, rowsum, dP, dS, dZ, dc, do, E, T, K, N)
+        finally:
+            lib.fql_tune_set_compute_units(old)
+        for cfg, out in outs.items():
+            bad = (~(out == ref_out).all(dim=1)).nonzero().flatten().tolist()
+            assert not bad, f"configuration {cfg} at {cus} workgroups: rows {bad[:8]} differ from the wide kernel"
+    ref = C.moe_grouped(P, S, Z, x, cnt, offs)
+    assert rel_fro(ref_out.cpu().numpy(), ref) < EXACT_REL_FRO

@@ -60,7 +60,7 @@ arr = np.array(buf[:], dtype=np.int64).reshape(8, 64)
 KT = K // 256
 per = 2 + KT + 2 + 1          # real0, clk0, KT stage starts, k-loop done, epilogue done, real1
 for b in range(8):
-    row = arr[b]; row = row[row > 0]
+    row = arr[b][:56]; row = row[row > 0]
     k = 0; v = 0
     while k + per <= len(row):
         r0, c0 = int(row[k]), int(row[k + 1])
@@ -71,3 +71,14 @@ for b in range(8):
         print(f"wg {b} visit {v}: wall {wall:6.1f} us  clock {ep / wall / 1000.0:.3f} GHz  first stage at {st[0]}  stages {d.tolist()}  "
               f"epilogue {ep - kd} cycles")
         k += per; v += 1
+if a.cfg >= 300:
+    print('stamps per workgroup:', [int((arr[b][:56] > 0).sum()) for b in range(8)])
+    # kernel-entry / prologue stamps (100 MHz): entry, row groups counted, tile table built, first stage parked; relative to
+    # the earliest entry of the eight traced workgroups
+    t00 = min(int(arr[b][56]) for b in range(8) if arr[b][56] > 0)
+    for b in range(8):
+        sp = [(int(arr[b][i]) - t00) / 100.0 for i in (56, 57, 58, 59)]
+        vis = [int(x) for x in arr[b][:56] if x > 0]
+        starts = [(vis[k] - t00) / 100.0 for k in range(0, len(vis) - per + 1, per)]
+        ends = [(vis[k + per - 1] - t00) / 100.0 for k in range(0, len(vis) - per + 1, per)]
+        print(f"wg {b}: entry {sp[0]:.2f} groups {sp[1]:.2f} table {sp[2]:.2f} primed {sp[3]:.2f} | visits start {starts} end {ends} (us after the first entry)")
