@@ -18,12 +18,13 @@
 //     is computed once per workgroup into LDS -- no vector load is ever waited for right after it is issued
 //     (vector-memory operations complete in order: such a wait would drain the whole prefetch queue).
 //
-// LDS image of a weight stage (unpacked, 256 B per weight row = 8 k-steps x 2 lane groups x 16 B):
-//   row n of the tile, slot s = 8 (ks & 1) + 2 (ks >> 1) + g  ->  byte n * 256 + 16 * (s ^ (n & 15))
-// conflict-free for the ds_read_b128 fragment reads (64 banks; a 16-lane group holds 16 different n & 15, hence 16
-// different slots) and for the parking ds_write_b128s (32 banks, groups of 8 lanes = the 8 chunks c of one row, which go
-// to slots c and 8 + c: 8 different slots mod 8 per instruction; slot 2 ks + g, the first layout, put chunks c and
-// c + 4 on the same banks: SQ_LDS_BANK_CONFLICT 8 cycles per store).
+// LDS image of a weight stage (unpacked; per k-step a plane of BN rows x 2 lane groups x 16 B, planes KSTRIDE apart):
+//   k-step ks, row n of the tile, lane group g  ->  byte ks * KSTRIDE + n * 32 + g * 16,   KSTRIDE = BN * 32 + 16
+// A fragment read (fixed ks, 32 rows x 2 groups) is 1 KiB contiguous: conflict-free, and every read of a stage is
+// ONE per-lane base register + an immediate offset (ks * KSTRIDE + j * 1024) -- the first layout, rows of 256 B with an
+// XOR swizzle of the 16-byte slots, needed 4 vector instructions per k-step to form the address.  The parking
+// ds_write_b128s (32 banks, groups of 8 lanes = the 8 chunks c = 2 v + g' of one row, which go to k-steps 2 v and 2 v + 1,
+// group g') are conflict-free through the 16 bytes added to the plane stride: plane 2 v starts 8 v banks further.
 //
 // Replaces (reference, CUDA): csrc/moe_int4_kernel.cu:17-136 and csrc/quantized_linear_kernel.cu:90-279.
 #pragma once
@@ -42,8 +43,6 @@ __device__ __forceinline__ void mfma_i8_vgpr_zero(v16i &acc, const v4i &w, const
     asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(acc) : "v"(w), "v"(a));
 }
 
-// byte offset (XOR-ed into a lane's fragment address) of k-step ks inside a weight row's 256-byte stage image
-__device__ __host__ constexpr int frag_xor(int ks) { return 16 * (8 * (ks & 1) + 2 * (ks >> 1)); }
 
 template <int L, int NF, int DEPTH = 8>
 struct W4Cfg {
@@ -53,7 +52,8 @@ struct W4Cfg {
     static constexpr int BM = 4 * FQL_MB;                    // 128 rows: one 32-row block per wave
     static constexpr int BN = 32 * NF;
     static constexpr int KS = FQL_KB / 32;                   // 8 k-steps per stage
-    static constexpr int W_STAGE = BN * FQL_KB;              // bytes of UNPACKED weights per stage
+    static constexpr int KSTRIDE = BN * 32 + 16;             // bytes between the k-step planes of a stage in LDS
+    static constexpr int W_STAGE = KS * KSTRIDE;             // bytes of UNPACKED weights per stage
     static constexpr int SZ_BYTES = 2 * 3 * BN * 4;          // two scale / zero-point / bias slices
     static constexpr int NTAB = 16;                          // tiles described ahead in LDS
     static constexpr int TAB_INTS = 8;
@@ -331,11 +331,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
     const int rowW = wave * 8 + (lane >> 3), chW = lane & 7;
     const int voffW = rowW * (K >> 1) + chW * 16;
     const int pieceW = 32 * (K >> 1);
-    const int wA0 = rowW * 256 + 16 * (chW ^ (rowW & 15));
-    const int wA1 = rowW * 256 + 16 * ((chW + 8) ^ (rowW & 15));
-    // fragment reads: row n = 32 j + l31, slot 8 (ks & 1) + 2 (ks >> 1) + g  ->  (l31 * 256 + 16 * (g ^ (l31 & 15))) ^ frag_xor(ks),
-    // + j * 8192
-    const int rF0 = l31 * 256 + 16 * (g ^ (l31 & 15));
+    const int wA0 = (chW & ~1) * C::KSTRIDE + rowW * 32 + (chW & 1) * 16;      // k-step 2 v, row, group g'   (+ i * 1024: piece i)
+    const int wA1 = wA0 + C::KSTRIDE;                                          // k-step 2 v + 1
+    // fragment reads: k-step ks, row n = 32 j + l31, group g  ->  ks * KSTRIDE + j * 1024 + (l31 * 32 + g * 16)
+    const int rF0 = l31 * 32 + g * 16;
     float *szbuf = reinterpret_cast<float *>(lds + 2 * C::W_STAGE);
 
     v4i bst[NF];                                             // one packed weight stage in flight (global -> VGPR)
@@ -373,8 +372,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         unpack8((uint32_t)bst[i][1], lo1, hi1);
         unpack8((uint32_t)bst[i][2], lo2, hi2);
         unpack8((uint32_t)bst[i][3], lo3, hi3);
-        *reinterpret_cast<v4i *>(buf + wA0 + i * 8192) = v4i{(int)lo0, (int)hi0, (int)lo1, (int)hi1};
-        *reinterpret_cast<v4i *>(buf + wA1 + i * 8192) = v4i{(int)lo2, (int)hi2, (int)lo3, (int)hi3};
+        *reinterpret_cast<v4i *>(buf + wA0 + i * 1024) = v4i{(int)lo0, (int)hi0, (int)lo1, (int)hi1};
+        *reinterpret_cast<v4i *>(buf + wA1 + i * 1024) = v4i{(int)lo2, (int)hi2, (int)lo3, (int)hi3};
     };
     auto issue_sz = [&](const GemmTile &tp) {
         const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void *)(scales + (size_t)tp.e * N), 0, N * 4, 0x00020000);
@@ -403,9 +402,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
     // the stage in `buf` (every slot plan reads its later ones itself).  The plans prefetch the coming step's fragments
     // with the CURRENT tile's fragment range, so at a visit boundary they are read again for the next tile's.
     auto read_first_frags = [&](const char *buf, int fb) {
-        const char *p = buf + fb * 8192 + (rF0 ^ frag_xor(0));
+        const char *p = buf + fb * 1024 + rF0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const v4i *>(p + j * 8192);
+        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const v4i *>(p + j * 1024);
     };
 
     // ---- kernel prologue: the state every visit starts from
@@ -485,7 +484,6 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         auto visit_body = [&](auto nact_tag) {
         constexpr int NACT = decltype(nact_tag)::value;      // fragments a wave holds in this kind of tile
         constexpr int NVA = (NACT == NF) ? NVF : 0;
-        const int nfr_k = cur.nfr;
         v16i acc[L][NACT - NVA > 0 ? NACT - NVA : 1];
         v16i accv[L][NVA > 0 ? NVA : 1];
         v4i afx[KS - D > 0 ? KS - D : 1][L];                 // ring slots D .. KS-1 of a short visit (never live between visits)
@@ -497,6 +495,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
             FQL_W4STAMP(ev++, 0);
             const char *sb = lds + (fs & 1) * C::W_STAGE;
             char *nb = lds + ((fs + 1) & 1) * C::W_STAGE;
+            // this wave's fragment reads of the stage: one per-lane base per buffer, everything else immediate offsets
+            // (formed per stage from an opaque copy: derived from the kernel-entry value they are loop invariants, hoisted
+            //  and spilled)
+            int rFo = rF0;
+            asm volatile("" : "+v"(rFo));
+            const char *sbf = sb + fbase * 1024 + rFo, *nbf = nb + fbase * 1024 + rFo;
             // what the loads of this stage fetch: weights two stages ahead, activations one stage ahead -- of this tile,
             // or of the next visit once this tile's K range is used up
             const bool w_here = kt + 2 < KT;
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
             // step offset is added): a single wave has ~6 issue slots per matrix instruction, and a select + add per
             // load and step spent them
             int sAq[3][L];
-            constexpr int RD = (NACT == NF || W4_SHORT_RING == 0 || (W4_SHORT_RING == 2 && NACT != 2) || (W4_SHORT_RING == 3 && NACT != 3)) ? D : KS;        // ring depth of this tile class
+            constexpr int RD = (NACT >= NF - 1 || W4_SHORT_RING == 0 || (W4_SHORT_RING == 2 && NACT != 2) || (W4_SHORT_RING == 3 && NACT != 3)) ? D : KS;        // ring depth of this tile class
             const bool last_stage = kt == KT - 1;
 #pragma unroll
             for (int l = 0; l < L; ++l) {
@@ -537,10 +541,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
                 //        fragment 5 (VGPR accumulators, skipped on narrow tiles): nothing; after it the piece's next load
                 // (the swizzled address is recomputed per step from an opaque copy: hoisted, its 8 values cost 8 registers
                 //  of a full register file and end up in scratch)
-                int rFo = rF0;
-                asm volatile("" : "+v"(rFo));
-                const char *fc = sb + fbase * 8192 + (rFo ^ frag_xor(ks));                  // this step's fragments (from the wave's first)
-                const char *fp = ((ks == KS - 1) ? nb : sb) + fbase * 8192 + (rFo ^ frag_xor((ks + 1) & 7));   // the coming step's
+                const char *fc = sbf + ks * C::KSTRIDE;                                     // this step's fragments (from the wave's first)
+                const char *fp = (ks == KS - 1) ? nbf : sbf + (ks + 1) * C::KSTRIDE;        // the coming step's
                 const bool park = ks < NF && !(W4_ABLATE & 1);
                 uint32_t up[8];
                 auto mm = [&](int j, int l) {                // one matrix instruction of fragment j < NF - NVF
@@ -572,15 +574,15 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
                                 ring(tk, l) = __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff0, sAq[0][l] + tk * 1024, 0);
                     }
                 };
-                auto frag = [&](const char *base, int j) { if (!(W4_ABLATE & 4)) wf[j] = *reinterpret_cast<const v4i *>(base + j * 8192); };
+                auto frag = [&](const char *base, int j) { if (!(W4_ABLATE & 4)) wf[j] = *reinterpret_cast<const v4i *>(base + j * 1024); };
                 auto unpack = [&](int i) {
                     if (!park) return;
                     unpack8((uint32_t)bst[ks % NF][i], up[2 * i], up[2 * i + 1]);
                     asm volatile("" : "+v"(up[2 * i]), "+v"(up[2 * i + 1]));              // pin the unpack to this slot
                 };
                 static_assert(NF == 6 && L == 3 && NVF == 1, "the slot plans below are written for 6 fragments x 3 limbs, the last fragment in VGPRs");
-                auto park0 = [&]() { if (park) *reinterpret_cast<v4i *>(nb + wA0 + ks * 8192) = v4i{(int)up[0], (int)up[1], (int)up[2], (int)up[3]}; };
-                auto park1 = [&]() { if (park) *reinterpret_cast<v4i *>(nb + wA1 + ks * 8192) = v4i{(int)up[4], (int)up[5], (int)up[6], (int)up[7]}; };
+                auto park0 = [&]() { if (park) *reinterpret_cast<v4i *>(nb + wA0 + ks * 1024) = v4i{(int)up[0], (int)up[1], (int)up[2], (int)up[3]}; };
+                auto park1 = [&]() { if (park) *reinterpret_cast<v4i *>(nb + wA1 + ks * 1024) = v4i{(int)up[4], (int)up[5], (int)up[6], (int)up[7]}; };
                 auto stage_barrier = [&]() {
                     if (ks == KS - 1) {
                         // every wave has parked the next stage (steps 0..NF-1) and holds the last fragments of this one
@@ -605,13 +607,33 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
                     mm(4, 0); fence(); frag(fp, 3); fence();
                     mm(4, 1); fence(); park0(); fence();
                     mm(4, 2); fence(); park1(); fence();
-                    if ((W4_ABLATE & 8) || NF - 1 < nfr_k) {     // (wave-uniform: the tile may be narrower than this fragment)
+                    // (tiles narrower than NF fragments take the 5-fragment body: no branch in this one)
 #pragma unroll
-                        for (int l = 0; l < L; ++l) {
-                            if (FIRST && ks == 0) mfma_i8_vgpr_zero(accv[l][0], wf[NF - 1], afr[ks % D][l]);
-                            else mfma_i8_vgpr(accv[l][0], wf[NF - 1], afr[ks % D][l]);
-                        }
+                    for (int l = 0; l < L; ++l) {
+                        if (FIRST && ks == 0) mfma_i8_vgpr_zero(accv[l][0], wf[NF - 1], afr[ks % D][l]);
+                        else mfma_i8_vgpr(accv[l][0], wf[NF - 1], afr[ks % D][l]);
                     }
+                } else if constexpr (NACT == 5) {
+                    // 128-row tiles of at most 5 fragments (the column tiling deals N / 32 fragments over the tiles as evenly as
+                    // possible: 5 and 6 at the headline shape): 15 matrix instructions, all accumulators in AGPRs, and
+                    // exactly one memory / unpack slot behind each -- this step's fragment 4, the three refills, the coming
+                    // step's fragments 0..3, the piece's four unpacks, its two parking stores, its next load
+                    mm(0, 0); fence(); frag(fc, 4); fence();
+                    mm(0, 1); fence(); refill(0); fence();
+                    mm(0, 2); fence(); refill(1); fence();
+                    stage_barrier();
+                    mm(1, 0); fence(); frag(fp, 0); fence();
+                    mm(1, 1); fence(); refill(2); fence();
+                    mm(1, 2); fence(); unpack(0); fence();
+                    mm(2, 0); fence(); frag(fp, 1); fence();
+                    mm(2, 1); fence(); unpack(1); fence();
+                    mm(2, 2); fence(); unpack(2); fence();
+                    mm(3, 0); fence(); frag(fp, 2); fence();
+                    mm(3, 1); fence(); unpack(3); fence();
+                    mm(3, 2); fence(); park0(); fence();
+                    mm(4, 0); fence(); frag(fp, 3); fence();
+                    mm(4, 1); fence(); park1(); fence();
+                    mm(4, 2); fence();
                 } else if constexpr (NACT == 3) {            // 33..64 rows: 9 matrix instructions, the same staging work
                     mm(0, 0); fence(); frag(fc, 2); fence();
                     mm(0, 1); fence(); refill(0); fence();
@@ -626,7 +648,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
                     park1();
                     ramp_up();
                 } else {                                     // <= 32 rows: 6 matrix instructions
-                    static_assert(NACT == 2, "tile classes: 6, 3 or 2 fragments per wave");
+                    static_assert(NACT == 2, "tile classes: 6, 5, 3 or 2 fragments per wave");
                     mm(0, 0); fence(); frag(fc, 1); fence();
                     mm(0, 1); fence(); refill(0); fence();
                     mm(0, 2); fence(); refill(1); fence();
@@ -757,7 +779,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         };   // visit_body
         // (one copy of K loop + epilogue per tile class, each with its own accumulators: a fragment skipped under a branch
         //  inside ONE copy turns the accumulators into phi nodes and the compiler then spills whole tuples around the epilogue)
-        if (cls == 4) visit_body(std::integral_constant<int, 6>{});
+        if (cls == 4 && cur.nfr == NF) visit_body(std::integral_constant<int, 6>{});
+        else if (cls == 4) visit_body(std::integral_constant<int, 5>{});
         else if (cls == 2) visit_body(std::integral_constant<int, 3>{});
         else visit_body(std::integral_constant<int, 2>{});
         FQL_W4STAMP(ev++, 0);
