@@ -177,7 +177,7 @@ __device__ __forceinline__ void act_padded_rows(int t0, int rows, int *s_p, int 
             const unsigned long long hit = __ballot(t < T && rel >= 0 && rel < xl.cnt);
             if (hit) {                                        // (ranges do not overlap: at most one expert per row)
                 const int src = __ffsll((long long)hit) - 1;
-                const int pv = __shfl(xl.pad_excl + rel, src, 64);
+                const int pv = wave_bcast(xl.pad_excl + rel, src);
                 if (lane == 0) s_p[rr] = pv;
             }
         }

@@ -150,14 +150,25 @@ struct ExpertLane {
     int tiles;          // m-tiles of this expert
 };
 
+// Inclusive prefix sum over the 64 lanes on the DPP data path: shifts inside the 16-lane rows, then the last lane of a
+// row broadcast into the next row(s) -- 6 adds of ~8 cycles each.  (The shuffle form, 6 dependent ds_bpermutes through
+// the LDS crossbar, cost ~100 cycles a step, and every persistent kernel runs four to nine of these scans before its
+// first load: 1.4 us of the GEMM's prologue on the in-kernel clock, tools/trace_step.py.)
 __device__ __forceinline__ int wave_incl_scan(int v, int lane)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int n = __shfl_up(v, o, 64);
-        if (lane >= o) v += n;
-    }
+    (void)lane;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);     // row_shr:1  (lanes without a source add 0)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
     return v;
+}
+// The value lane `src` holds, for a wave-uniform src: v_readlane instead of a trip through the LDS crossbar.
+__device__ __forceinline__ int wave_bcast(int v, int src)
+{
+    return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src));
 }
 
 // Processes experts [base, base + 64); carry_pad / carry_tile are the totals of the experts before `base`
@@ -184,8 +195,8 @@ __device__ __forceinline__ ExpertLane expert_chunk_scan(int off_raw, int cnt_raw
     const int tile_incl = wave_incl_scan(r.tiles, lane);
     r.pad_excl = carry_pad + pad_incl - pad;
     r.tile_excl = carry_tile + tile_incl - r.tiles;
-    carry_pad += __shfl(pad_incl, 63, 64);
-    carry_tile += __shfl(tile_incl, 63, 64);
+    carry_pad += wave_bcast(pad_incl, 63);
+    carry_tile += wave_bcast(tile_incl, 63);
     return r;
 }
 __device__ __forceinline__ ExpertLane expert_chunk(const int32_t *tpe, const int32_t *offs, int E, int T, int bm,
@@ -200,7 +211,7 @@ __device__ __forceinline__ ExpertLane expert_chunk(const int32_t *tpe, const int
     const int tile_incl = wave_incl_scan(r.tiles, lane);
     r.pad_excl = carry_pad + pad_incl - pad;
     r.tile_excl = carry_tile + tile_incl - r.tiles;
-    carry_pad += __shfl(pad_incl, 63, 64);
-    carry_tile += __shfl(tile_incl, 63, 64);
+    carry_pad += wave_bcast(pad_incl, 63);
+    carry_tile += wave_bcast(tile_incl, 63);
     return r;
 }

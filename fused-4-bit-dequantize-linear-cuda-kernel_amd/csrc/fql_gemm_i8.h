@@ -198,8 +198,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_i8_kernel(
                 const unsigned long long hit = __ballot(ms >= x.tile_excl && ms < x.tile_excl + x.tiles);
                 if (hit) {
                     const int src = __ffsll((long long)hit) - 1;
-                    const int lo = __shfl(x.lo, src, 64), cnt = __shfl(x.cnt, src, 64);
-                    const int te = __shfl(x.tile_excl, src, 64), pe = __shfl(x.pad_excl, src, 64);
+                    const int lo = wave_bcast(x.lo, src), cnt = wave_bcast(x.cnt, src);
+                    const int te = wave_bcast(x.tile_excl, src), pe = wave_bcast(x.pad_excl, src);
                     tp.e = base + src;
                     tp.row0 = lo + (ms - te) * C::BM;
                     tp.prow0 = pe + (ms - te) * C::BM;

@@ -138,8 +138,8 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void gemm_i8_rows16_kernel(
                 const unsigned long long hit = __ballot(lane < E && ms >= te && ms < te + tiles_e);
                 if (hit) {
                     const int src = __ffsll((long long)hit) - 1;
-                    const int lo_s = __shfl(lo, src, 64), cnt_s = __shfl(cnt, src, 64);
-                    const int te_s = __shfl(te, src, 64), pe_s = __shfl(pe, src, 64);
+                    const int lo_s = wave_bcast(lo, src), cnt_s = wave_bcast(cnt, src);
+                    const int te_s = wave_bcast(te, src), pe_s = wave_bcast(pe, src);
                     tp.e = src;
                     tp.row0 = lo_s + (ms - te_s) * C::BM;
                     tp.prow0 = pe_s + (ms - te_s) * C::BM;    // experts are padded to 32 rows: a 16-row tile is one half block
@@ -154,8 +154,8 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void gemm_i8_rows16_kernel(
                     const unsigned long long hit = __ballot(ms >= x.tile_excl && ms < x.tile_excl + x.tiles);
                     if (hit && base > 0) {
                         const int src = __ffsll((long long)hit) - 1;
-                        const int lo = __shfl(x.lo, src, 64), cnt = __shfl(x.cnt, src, 64);
-                        const int te = __shfl(x.tile_excl, src, 64), pe = __shfl(x.pad_excl, src, 64);
+                        const int lo = wave_bcast(x.lo, src), cnt = wave_bcast(x.cnt, src);
+                        const int te = wave_bcast(x.tile_excl, src), pe = wave_bcast(x.pad_excl, src);
                         tp.e = base + src;
                         tp.row0 = lo + (ms - te) * C::BM;
                         tp.prow0 = pe + (ms - te) * C::BM;

@@ -152,10 +152,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         r.big_excl = cb + big_incl - r.nbig;
         r.c2_excl = c2 + c2_incl - r.c2;
         r.c1_excl = c1 + c1_incl - r.c1;
-        carry_pad += __shfl(pad_incl, 63, 64);
-        cb += __shfl(big_incl, 63, 64);
-        c2 += __shfl(c2_incl, 63, 64);
-        c1 += __shfl(c1_incl, 63, 64);
+        carry_pad += wave_bcast(pad_incl, 63);
+        cb += wave_bcast(big_incl, 63);
+        c2 += wave_bcast(c2_incl, 63);
+        c1 += wave_bcast(c1_incl, 63);
         return r;
     };
     int MB = m_slots, MC2 = 0, MC1 = 0;                      // row tiles per cost group
@@ -239,8 +239,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
                 const unsigned long long hit = __ballot(mine);
                 if (hit) {
                     const int src = __ffsll((long long)hit) - 1;
-                    const int lo = __shfl(x.lo, src, 64), cnt = __shfl(x.cnt, src, 64);
-                    const int be = __shfl(x.big_excl, src, 64), pe = __shfl(x.pad_excl, src, 64);
+                    const int lo = wave_bcast(x.lo, src), cnt = wave_bcast(x.cnt, src);
+                    const int be = wave_bcast(x.big_excl, src), pe = wave_bcast(x.pad_excl, src);
                     const int slice = grp == 0 ? ms - be : cnt / C::BM;       // the tail is the slice after the full ones
                     tp.e = base + src;
                     tp.row0 = lo + slice * C::BM;
@@ -729,6 +729,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
             for (int j = 0; j < NACT; ++j) {
                 __builtin_amdgcn_sched_barrier(0);           // (register pressure: no fragment's reads before its turn)
                 if (j >= nfr_c) continue;
+                if (ev <= 21) FQL_W4STAMP(42 + j, 0);        // (trace builds: the first visit's epilogue, fragment by fragment)
                 float o[4][4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {

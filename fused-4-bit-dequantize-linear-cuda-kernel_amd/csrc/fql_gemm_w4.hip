@@ -18,6 +18,7 @@ int launch_w4(const FqlW4Args &a)
         attr.set[dev] = true;
     }
     (void)hipGetLastError();
+    // (a cooperative launch of the same kernel, hipLaunchCooperativeKernel, cost +18 us per step: profiles/r03_ab_cooperative_launch.txt)
     hipLaunchKernelGGL(kern, dim3((unsigned)a.blocks), dim3(C::THREADS), C::LDS_BYTES, a.stream, a.limbs, a.delta, a.rowsum,
                        a.packed, a.scales, a.zps, a.out, a.out_kind, a.tpe, a.offs, a.E, a.T, a.K, a.Kp, a.MBT, a.N,
                        a.n_tiles, a.m_slots, a.scratch, a.bias, a.n_alt);

@@ -65,7 +65,7 @@ for b in range(8):
     row = w4[b]
     if row[56] <= 0:
         continue
-    vis = [int(v) for v in row[:56] if v > 0]
+    vis = [int(v) for v in row[:42] if v > 0]
     txt = []
     for k in range(0, len(vis) - per + 1, per):
         c0 = vis[k + 1]

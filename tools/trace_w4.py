@@ -60,7 +60,7 @@ arr = np.array(buf[:], dtype=np.int64).reshape(8, 64)
 KT = K // 256
 per = 2 + KT + 2 + 1          # real0, clk0, KT stage starts, k-loop done, epilogue done, real1
 for b in range(8):
-    row = arr[b][:56]; row = row[row > 0]
+    row = arr[b][:42]; row = row[row > 0]
     k = 0; v = 0
     while k + per <= len(row):
         r0, c0 = int(row[k]), int(row[k + 1])
@@ -78,7 +78,11 @@ if a.cfg >= 300:
     t00 = min(int(arr[b][56]) for b in range(8) if arr[b][56] > 0)
     for b in range(8):
         sp = [(int(arr[b][i]) - t00) / 100.0 for i in (56, 57, 58, 59)]
-        vis = [int(x) for x in arr[b][:56] if x > 0]
+        vis = [int(x) for x in arr[b][:42] if x > 0]
         starts = [(vis[k] - t00) / 100.0 for k in range(0, len(vis) - per + 1, per)]
         ends = [(vis[k + per - 1] - t00) / 100.0 for k in range(0, len(vis) - per + 1, per)]
+        fr = [int(x) for x in arr[b][42:48] if x > 0]
+        if len(fr) > 1 and len(vis) >= per:
+            kd0 = vis[2 + KT]; ep0 = vis[3 + KT]
+            print(f"wg {b}: first visit's epilogue, cycles per fragment {np.diff([kd0] + fr + [ep0]).tolist()} (first entry: K loop end -> fragment 0)")
         print(f"wg {b}: entry {sp[0]:.2f} groups {sp[1]:.2f} table {sp[2]:.2f} primed {sp[3]:.2f} | visits start {starts} end {ends} (us after the first entry)")
