@@ -4,7 +4,7 @@ set -o pipefail
 export TMPDIR=/tmp
 for spec in "config5_fp8:--experts 64 --hidden 7168 --ffn 18432 --tokens 512 --top-k 6 --weight-sets 2 --precision fp8" "decode32:--tokens 32"; do
   tag=${spec%%:*}; args=${spec#*:}
-  out=gpurun_out/prof_r02_$tag; mkdir -p $out
+  out=gpurun_out/prof_${PROF_ROUND:-r03}_$tag; mkdir -p $out
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-side-modes $args > $out/bench_trace.log 2>&1
   for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"; do
     name=$(echo $set | tr ' ' '_' | cut -c1-40)
