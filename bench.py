@@ -43,6 +43,9 @@ def parse():
                     help="distinct weight copies rotated through so that consecutive steps cannot be served "
                          "from the 256 MB Infinity Cache (4 x 180 MB); 1 = warm-cache numbers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--one-launch", type=int, default=-1, choices=[-1, 0, 1],
+                    help="A/B switch (tuning hook fql_tune_set_fused): 1 = pre-pass as the GEMM kernel's first phase, 0 = two launches, "
+                         "-1 = the library's default")
     ap.add_argument("--no-side-modes", action="store_true",
                     help="skip the opt-in precision / float16 side measurements (profiling runs: one kernel variant only)")
     ap.add_argument("--experts", type=int, default=8)
@@ -214,6 +217,9 @@ def main():
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if a.one_launch >= 0:
+        from fused_int4_amd import _native
+        _native.lib().fql_tune_set_fused(a.one_launch)
     # Rehearsal mode (FQL_BENCH_BACKEND=gloo): several ranks share the visible card(s) and the collectives go
     # through host memory over gloo -- exercises this file's multi-rank path on a 1-GPU box; never a measurement.
     rehearsal = os.environ.get("FQL_BENCH_BACKEND", "nccl") == "gloo"

@@ -203,20 +203,25 @@ __device__ __forceinline__ int act_row16_reduce(int v, Op op)
 // Debug builds (-DFQL_TRACE, tools/trace_step.py): thread 0 of the first and the last 8 workgroups stamps the 100 MHz
 // clock at the phase boundaries of the pre-pass.
 #if defined(FQL_TRACE)
-__device__ unsigned long long fql_trace_act[16 * 16];
+static __device__ unsigned long long fql_trace_act[16 * 16];   // (one copy per translation unit that includes this header)
 #define FQL_ASTAMP(i) do { const int sl_ = (int)blockIdx.x < 8 ? (int)blockIdx.x : ((int)blockIdx.x + 8 >= rblocks && (int)blockIdx.x < rblocks ? 8 + (int)blockIdx.x - (rblocks - 8) : -1); \
     if (sl_ >= 0 && sl_ < 16 && threadIdx.x == 0) fql_trace_act[sl_ * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define FQL_ASTAMP(i) do { } while (0)
 #endif
 
-template <int L, bool VEC, int IN, bool GATE = false, bool F8OUT = false, int AR = ACT_ROWS>
-__global__ __launch_bounds__(256) void act_fused_kernel(
+// The pre-pass of ONE group of AR grouped rows t0 .. t0 + AR - 1 by a 256-thread workgroup: the body of act_fused_kernel, and
+// (round 3) the first phase of the one-launch form of pre-pass + GEMM (fql_gemm_w4.h, FUSED).  Static LDS only; a caller that
+// runs it more than once synchronises in between.
+// WT: every global store goes straight to device-coherent memory (sc1): the one-launch form's consumers sit on other XCDs,
+// whose L2s are not coherent with this one's, and a release fence instead (L2 write-back) cost 10-20 us per workgroup.
+template <int L, bool VEC, int IN, bool GATE = false, bool F8OUT = false, int AR = ACT_ROWS, bool WT = false>
+__device__ __forceinline__ void act_rows(
     const void *__restrict__ xin, const int32_t *__restrict__ gather, int n_src, float *__restrict__ delta,
     int32_t *__restrict__ rowsum, int8_t *__restrict__ limbs, int T, int K, int KB, int MBT, int rblocks,
-    void *__restrict__ out, int out_es, int N, const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
-    int E, const float *__restrict__ row_weight)
+    const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs, int E, const float *__restrict__ row_weight, int t0)
 {
+    (void)rblocks;
     constexpr int ES = (IN == 0) ? 4 : 2;
     // row_weight (optional): per grouped row, copied into the plane behind delta's set(s) for the GEMM's epilogue
     constexpr int DSETS = (L >= 2 && !F8OUT && FQL_RES_ENABLED) ? 2 : 1;         // bytes per element of x
@@ -235,14 +240,8 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     FQL_ASTAMP(0);
 
-    if ((int)blockIdx.x >= rblocks) {             // ---- coverage workgroups: 256 rows of `out` each
-        act_zero_uncovered((int)blockIdx.x - rblocks, out, out_es, N, tpe, offs, E, T);
-        return;
-    }
-
-    // ---- this workgroup's grouped rows t0 .. t0 + R_ - 1 (the last workgroup may hold rows past T: they re-read row
+    // ---- this workgroup's grouped rows t0 .. t0 + R_ - 1 (the last group may hold rows past T: they re-read row
     //      T - 1 and store nothing)
-    const int t0 = blockIdx.x * R_;
     if (t0 >= T) return;
     const int r = tid & (R_ - 1), col = tid / R_;   // row of the workgroup, chunk column
     const int trow = t0 + r;
@@ -395,7 +394,9 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
     }
     const int e = act_exponent<L>(bad ? 0.0f : m);
     const float inv = bad ? 0.0f : ldexpf(1.0f, -e);           // non-finite row: limbs 0, delta NaN -> outputs NaN
-    if (tid < R_ && tok >= 0) { delta[tok] = bad ? __builtin_nanf("") : ldexpf(1.0f, e); if (row_weight != nullptr) delta[(size_t)DSETS * T + tok] = row_weight[tok]; }
+    auto put_f = [&](float *ptr, float v) { if (WT) __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *ptr = v; };
+    auto put_i = [&](int32_t *ptr, int v) { if (WT) __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *ptr = v; };
+    if (tid < R_ && tok >= 0) { put_f(delta + tok, bad ? __builtin_nanf("") : ldexpf(1.0f, e)); if (row_weight != nullptr) put_f(delta + (size_t)DSETS * T + tok, row_weight[tok]); }
 
     // ---- pass 2: quantise and store.  Pass 3 (rows flagged as heavy-tailed only, L >= 2): the RESIDUAL of pass 2's
     //      rounding, r = x / delta - X in [-1/2, 1/2] (exact in float32), as a second fixed-point value
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
                     for (int i = 0; i < 4; ++i) sums[l] = __builtin_amdgcn_sdot4((int)w[l][i], 0x01010101, sums[l], false);
                     int8_t *dst = base + (((size_t)l * KB + kb) * MBT + mb) * 8192 + ((ks * 64) + g * 32 + r32) * 16;
                     if (store && tok >= 0) {
-                        if (FQL_LIMB_WT) store16_wt(dst, v4i{(int)w[l][0], (int)w[l][1], (int)w[l][2], (int)w[l][3]});
+                        if (FQL_LIMB_WT || WT) store16_wt(dst, v4i{(int)w[l][0], (int)w[l][1], (int)w[l][2], (int)w[l][3]});
                         else *reinterpret_cast<v4i *>(dst) = v4i{(int)w[l][0], (int)w[l][1], (int)w[l][2], (int)w[l][3]};
                     }
                 }
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
         int flag = 0;
         if (tok >= 0) {
 #pragma unroll
-            for (int l = 0; l < L; ++l) rowsum[(size_t)l * T + tok] = total_sum(tid, l);
+            for (int l = 0; l < L; ++l) put_i(rowsum + (size_t)l * T + tok, total_sum(tid, l));
             if (RES) {
                 float tot = 0.0f;                                                      // ||x / delta||^2
 #pragma unroll
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
                 }
                 const float lim = (float)K * (L == 3 ? 8.3333e10f : 1.3333e6f);                    // K / (12 P^2)
                 flag = (!bad && m != 0.0f && tot < lim && e - RBITS >= -126) ? 1 : 0;
-                delta[(size_t)T + tok] = flag ? ldexpf(1.0f, e - RBITS) : 0.0f;
+                put_f(delta + (size_t)T + tok, flag ? ldexpf(1.0f, e - RBITS) : 0.0f);
             }
         }
         if (RES) s_flag[tid] = flag;
@@ -532,6 +533,21 @@ __global__ __launch_bounds__(256) void act_fused_kernel(
     __syncthreads();
     if (tid < R_ && tok >= 0 && s_flag[tid]) {
 #pragma unroll
-        for (int l = 0; l < L; ++l) rowsum[(size_t)(L + l) * T + tok] = total_sum(tid, l);
+        for (int l = 0; l < L; ++l) put_i(rowsum + (size_t)(L + l) * T + tok, total_sum(tid, l));
     }
+}
+
+template <int L, bool VEC, int IN, bool GATE = false, bool F8OUT = false, int AR = ACT_ROWS>
+__global__ __launch_bounds__(256) void act_fused_kernel(
+    const void *__restrict__ xin, const int32_t *__restrict__ gather, int n_src, float *__restrict__ delta,
+    int32_t *__restrict__ rowsum, int8_t *__restrict__ limbs, int T, int K, int KB, int MBT, int rblocks,
+    void *__restrict__ out, int out_es, int N, const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
+    int E, const float *__restrict__ row_weight)
+{
+    if ((int)blockIdx.x >= rblocks) {             // ---- coverage workgroups: 256 rows of `out` each
+        act_zero_uncovered((int)blockIdx.x - rblocks, out, out_es, N, tpe, offs, E, T);
+        return;
+    }
+    act_rows<L, VEC, IN, GATE, F8OUT, AR>(xin, gather, n_src, delta, rowsum, limbs, T, K, KB, MBT, rblocks, tpe, offs, E, row_weight,
+                                          (int)blockIdx.x * AR);
 }

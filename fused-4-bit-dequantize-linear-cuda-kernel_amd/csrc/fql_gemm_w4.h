@@ -30,6 +30,8 @@
 #pragma once
 #include "fql_common.h"
 #include "fql_gemm_i8.h"
+#include "fql_act_quant.h"
+#include "fql_w4_launch.h"
 
 // v_mfma_i32_32x32x32_i8 with the accumulator in VGPRs (the builtin's accumulators are AGPRs in a 512-register kernel).
 // Hazards the compiler cannot see are excluded by construction: two of these on one accumulator are always separated
@@ -79,14 +81,22 @@ __device__ unsigned long long fql_trace_w4[8 * 64];
 #define FQL_W4STAMP(i, real) do { } while (0)
 #endif
 
-template <int L, int NF, int DEPTH>
+// FUSED (round 3): ONE launch for pre-pass + GEMM.  Every workgroup first quantises its share of the grouped rows (4 at a
+// time, act_rows of fql_act_quant.h -- the pre-pass kernel's own body) while its first tile's weight stage is already on
+// its way from HBM, publishes each group of rows with a release store of the launch's token, and waits for the row groups
+// of ITS OWN tiles only.  No workgroup ever depends on another one for good: after a bounded number of polls it quantises
+// the rows it is waiting for itself (the same bytes, so the race with their owner is benign) -- a launch can therefore not
+// hang however the device schedules its workgroups (two such launches on two streams, a busy device), it only gets slower.
+// What it saves (tools/trace_step.py): the launch boundary between the two kernels (~3 us) and the GEMM's prologue
+// (expert scan, tile table, first weight stage: ~6 us), which now run under the pre-pass.
+template <int L, int NF, int DEPTH, bool FUSED = false>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
     const int8_t *__restrict__ limbs, const float *__restrict__ delta,
     const int32_t *__restrict__ rowsum, const uint8_t *__restrict__ packed,
     const float *__restrict__ scales, const float *__restrict__ zps, void *__restrict__ out, int out_kind_flags,
     const int32_t *__restrict__ tpe, const int32_t *__restrict__ offs,
     int E, int T, int K, int Kp, int MBT, int N, int n_tiles_min, int m_slots, float *__restrict__ res_scratch,
-    const float *__restrict__ bias, int n_tiles_alt)
+    const float *__restrict__ bias, int n_tiles_alt, FqlW4Fused fz)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     using C = W4Cfg<L, NF, DEPTH>;
@@ -200,7 +210,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
     n_tiles = __builtin_amdgcn_readfirstlane(n_tiles);
     const int n_big = MB * n_tiles, n_c2 = MC2 * n_tiles, n_c1 = MC1 * n_tiles;
     n_real = __builtin_amdgcn_readfirstlane(n_big + n_c2 + n_c1);
-    if ((int)blockIdx.x >= n_real) return;
+    const bool has_tiles = (int)blockIdx.x < n_real;
+    if (!FUSED && !has_tiles) return;
     FQL_W4STAMP(57, 1);                                      // (row groups counted)
     const int f_base = n_frag / n_tiles, f_rem = n_frag - f_base * n_tiles;
 
@@ -410,6 +421,75 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
     // ---- kernel prologue: the state every visit starts from
     //        LDS buffer fs & 1 holds stage 0 of the visit, bst its stage 1 (in flight), afr the A fragments of its
     //        stage 0 (in flight), wf the weight fragments of its k-step 0, sz[parity] its scale / zero-point slice
+    // ---- FUSED: the pre-pass as this kernel's first phase (see the comment at the kernel's head)
+    __shared__ int s_fused_missing;
+    // (the by-value argument struct taken apart here: captured whole by the lambdas below it is copied to scratch memory)
+    const void *const fz_x = fz.x;
+    const int32_t *const fz_gather = fz.gather;
+    const int fz_n_src = fz.n_src, fz_spin_limit = fz.spin_limit;
+    const float *const fz_row_weight = fz.row_weight;
+    unsigned long long *const fz_flags = fz.flags;
+    const unsigned long long fz_token = fz.token;
+    // (always_inline: an out-of-line lambda takes its captures by address, which puts T, K, the pointers ... into scratch memory)
+    auto fused_rows = [&](int grp) __attribute__((always_inline)) {   // one group of 4 grouped rows, end to end
+        act_rows<L, true, 0, false, false, 4, true>(fz_x, fz_gather, fz_n_src, const_cast<float *>(delta), const_cast<int32_t *>(rowsum),
+                                              const_cast<int8_t *>(limbs), T, K, KT, MBT, 0, tpe, offs, E, fz_row_weight, grp * 4);
+    };
+    auto fused_phase1 = [&]() __attribute__((always_inline)) {
+        const int ngroups = (T + 3) >> 2;
+        for (int grp = (int)blockIdx.x; grp < ngroups; grp += (int)gridDim.x) {
+            fused_rows(grp);
+            // this thread's limb / delta / row-sum stores were write-through (sc1): once they have completed they are in
+            // device-coherent memory; no L2 write-back (a release fence here: 10-20 us per workgroup)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(fz_flags + grp, fz_token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // rows of `out` no expert covers (reference semantics: torch::zeros, csrc/moe_int4_kernel.cu:109)
+        if (tpe != nullptr)
+            for (int zb = (int)blockIdx.x; zb * 256 < T; zb += (int)gridDim.x) act_zero_uncovered(zb, out, out_kind == 0 ? 4 : 2, N, tpe, offs, E, T);
+    };
+    // the row groups of this workgroup's own tiles: poll their flags (bounded), quantise what is still missing myself
+    auto fused_wait = [&]() __attribute__((always_inline)) {
+        if (tid == 0) s_fused_missing = 0;
+        __syncthreads();
+        bool miss = false;
+        for (int j = 0; j < NPR; ++j) {
+            const int *p = tab + (wave + j * C::NW) * C::TAB_INTS;
+            const int row0 = __builtin_amdgcn_readfirstlane(p[1]), rows = __builtin_amdgcn_readfirstlane(p[3]);
+            if (!(__builtin_amdgcn_readfirstlane(p[6]) & 1) || rows <= 0) continue;
+            const int g0 = row0 >> 2, g1 = (row0 + rows - 1) >> 2;
+            int spins = 0;
+            for (;;) {
+                bool all_ok = true;
+                for (int grp = g0 + lane; grp <= g1; grp += 64)
+                    all_ok = all_ok && (__hip_atomic_load(fz_flags + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == fz_token);
+                if (__all(all_ok)) break;
+                if (++spins > fz_spin_limit) { miss = true; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        if (miss && lane == 0) s_fused_missing = 1;
+        __syncthreads();
+        if (s_fused_missing) {                               // (never on an idle device: the owners are co-resident and as fast as we are)
+            for (int i = 0; i < C::NTAB; ++i) {
+                const int *p = tab + i * C::TAB_INTS;
+                const int row0 = __builtin_amdgcn_readfirstlane(p[1]), rows = __builtin_amdgcn_readfirstlane(p[3]);
+                if (!(__builtin_amdgcn_readfirstlane(p[6]) & 1) || rows <= 0) continue;
+                for (int grp = row0 >> 2; grp <= ((row0 + rows - 1) >> 2); ++grp) {
+                    __syncthreads();
+                    fused_rows(grp);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the rows other workgroups wrote: not from this XCD's stale cache lines
+        __syncthreads();
+    };
+    if constexpr (FUSED) {
+        if (!has_tiles) { fused_phase1(); return; }          // no tile for this workgroup: its share of the rows, then done
+    }
+
     fill_table(0, std::false_type{});
     FQL_W4STAMP(58, 1);                                      // (tile table in LDS)
     int ti = 0;                                              // tile index of this workgroup (table slot ti % NTAB)
@@ -419,11 +499,23 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
     {
         const __amdgpu_buffer_rsrc_t rs = weight_rsrc(cur.e);
         const int sW = w_base(cur);
-        // which limb set the first visit reads depends on the heavy-tail probe: its round trip runs under the weights'
-        probe_issue();
-        issue_weights(rs, sW, cur.nfr);
-        issue_sz(cur);
-        probe_finish();
+        if constexpr (FUSED) {
+            // the first weight stage leaves for HBM before the rows are quantised; the probe after the rows exist
+            issue_weights(rs, sW, cur.nfr);
+            issue_sz(cur);
+            fused_phase1();
+            FQL_W4STAMP(60, 1);                              // (own rows quantised and published)
+            fused_wait();
+            FQL_W4STAMP(61, 1);                              // (the tiles' rows are there)
+            probe_issue();
+            probe_finish();
+        } else {
+            // which limb set the first visit reads depends on the heavy-tail probe: its round trip runs under the weights'
+            probe_issue();
+            issue_weights(rs, sW, cur.nfr);
+            issue_sz(cur);
+            probe_finish();
+        }
         cur = load_tile(0);
         if constexpr (!RES) cur.rp = 0;
         const int sA = a_base(cur);

@@ -5,11 +5,11 @@
 
 namespace {
 struct PerDeviceFlagW4 { bool set[64] = {}; };
-template <int L, int NF, int D>
+template <int L, int NF, int D, bool FUSED = false>
 int launch_w4(const FqlW4Args &a)
 {
     using C = W4Cfg<L, NF, D>;
-    auto kern = gemm_w4_kernel<L, NF, D>;
+    auto kern = gemm_w4_kernel<L, NF, D, FUSED>;
     static PerDeviceFlagW4 attr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -21,15 +21,16 @@ int launch_w4(const FqlW4Args &a)
     // (a cooperative launch of the same kernel, hipLaunchCooperativeKernel, cost +18 us per step: profiles/r03_ab_cooperative_launch.txt)
     hipLaunchKernelGGL(kern, dim3((unsigned)a.blocks), dim3(C::THREADS), C::LDS_BYTES, a.stream, a.limbs, a.delta, a.rowsum,
                        a.packed, a.scales, a.zps, a.out, a.out_kind, a.tpe, a.offs, a.E, a.T, a.K, a.Kp, a.MBT, a.N,
-                       a.n_tiles, a.m_slots, a.scratch, a.bias, a.n_alt);
+                       a.n_tiles, a.m_slots, a.scratch, a.bias, a.n_alt, a.fz);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 }  // namespace
 
 int fql_w4_launch(int L, int nf, int depth, const FqlW4Args &a)
 {
-    if (L == 3 && nf == 6 && depth == 8) return launch_w4<3, 6, 8>(a);
-    if (L == 3 && nf == 6 && depth == 4) return launch_w4<3, 6, 4>(a);
+    if (L == 3 && nf == 6 && depth == 8 && !a.fused) return launch_w4<3, 6, 8>(a);
+    if (L == 3 && nf == 6 && depth == 4) return a.fused ? launch_w4<3, 6, 4, true>(a) : launch_w4<3, 6, 4>(a);
+    if (a.fused) return -2;
     return -2;
 }
 int fql_w4_bn(int L, int nf) { (void)L; return 32 * nf; }

@@ -17,6 +17,8 @@
 #include "fql_quantize.h"
 #include "fql_routing.h"
 #include "fql_w4_launch.h"
+#include <atomic>
+#include <random>
 
 namespace {
 
@@ -95,6 +97,10 @@ struct Workspace {            // (every member has a default: a hand-filled Work
     float *scratch = nullptr;          // workgroup-private float32 partials of the residual pass (heavy-tailed rows), or nullptr
     const float *bias = nullptr;       // optional per-column bias [N] added to the final outputs (not workspace memory: rides along)
     const float *row_weight = nullptr; // optional per-row output weight [T] (caller's array: the pre-pass copies it into the plane behind delta)
+    unsigned long long *flags = nullptr;   // one-launch form (fql_gemm_w4.h, FUSED): one word per group of 4 grouped rows
+    const void *fuse_x = nullptr;      // one-launch form requested: the float32 rows the GEMM kernel quantises itself (ride along, like bias)
+    const int32_t *fuse_gather = nullptr;
+    int fuse_n_src = 0;
     size_t bytes = 0;
 };
 
@@ -113,14 +119,16 @@ inline Workspace carve(void *base, int L, int T, int E, int Kp, bool res)
     const size_t lb = round16(sets * limb_bytes(L, T, E, Kp));
     const size_t db = round16((size_t)(sets + 1) * T * sizeof(float));       // + the row-weight plane (fql_moe_gather_scaled_fwd_f32)
     const size_t rb = round16((size_t)sets * L * T * sizeof(int32_t));
+    const size_t fb = (L == 3 && res) ? round16(((size_t)T + 3) / 4 * sizeof(unsigned long long)) : 0;   // row-group flags of the one-launch form
     char *p = static_cast<char *>(base);
     w.limbs = reinterpret_cast<int8_t *>(p);
     w.delta = reinterpret_cast<float *>(p + lb);
     w.rowsum = reinterpret_cast<int32_t *>(p + lb + db);
-    w.scratch = res ? reinterpret_cast<float *>(p + lb + db + rb) : nullptr;
+    w.flags = fb ? reinterpret_cast<unsigned long long *>(p + lb + db + rb) : nullptr;
+    w.scratch = res ? reinterpret_cast<float *>(p + lb + db + rb + fb) : nullptr;
     w.bias = nullptr;
     w.row_weight = nullptr;
-    w.bytes = lb + db + rb + (res ? res_scratch_bytes() : 0);
+    w.bytes = lb + db + rb + fb + (res ? res_scratch_bytes() : 0);
     return w;
 }
 
@@ -376,6 +384,33 @@ int launch_rows16_cfg(const Workspace &w, const uint8_t *packed, const float *sc
     return hipGetLastError() == hipSuccess ? FQL_OK : FQL_ERR_LAUNCH;
 }
 
+// One launch for pre-pass + GEMM (fql_gemm_w4.h, FUSED): tuning switch, the polls a workgroup spends on another one's rows
+// before it quantises them itself, and the launch token (unique per launch: a flag word of an earlier launch, or of
+// whatever the workspace held before, never equals it -- 2^-64 for arbitrary memory).
+int g_fused = 0;
+int g_fused_spin = 20000;
+inline unsigned long long next_fused_token()
+{
+    static const unsigned long long salt = ((unsigned long long)std::random_device{}() << 32) | 0x100000000ull;
+    static std::atomic<unsigned> counter{1};
+    return salt ^ (unsigned long long)counter.fetch_add(1, std::memory_order_relaxed);
+}
+// The one-launch form keeps its tile list in the 16-entry LDS table: every workgroup must get by with one table.
+inline bool w4_fusable(int nf, const int32_t *tpe, int E, int T, int N)
+{
+    const int BM = 128, BN = 32 * nf;
+    const int cus = compute_units();
+    const int m_slots = (tpe == nullptr) ? (T + BM - 1) / BM : T / BM + E;
+    const int groups = (tpe == nullptr) ? 1 : E;
+    const long long m_even = (long long)groups * (((T + groups - 1) / groups + BM - 1) / BM);
+    const int n_tiles = (N + BN - 1) / BN;
+    const int n_alt = balanced_n_tiles(N, BN / 32, m_even, cus);
+    long long worst = (long long)(n_alt > n_tiles ? n_alt : n_tiles) * m_slots;
+    if (worst <= 0) return false;
+    const long long blocks = worst > cus ? cus : worst;
+    return (worst + blocks - 1) / blocks <= 16;
+}
+
 // The one-wave-per-SIMD kernel: same tiles and column split as the wide kernel's 128 x 192 configuration.
 int launch_w4_cfg(int L, int nf, int depth, const Workspace &w, const uint8_t *packed, const float *scales, const float *zps,
                   void *out, int out_dtype, const int32_t *tpe, const int32_t *offs, int E, int T, int K, int Kp, int MBT,
@@ -402,6 +437,10 @@ int launch_w4_cfg(int L, int nf, int depth, const Workspace &w, const uint8_t *p
     a.n_tiles = n_tiles; a.m_slots = m_slots; a.n_alt = n_alt;
     a.scratch = w.scratch; a.bias = w.bias;
     a.blocks = blocks; a.stream = st;
+    if (w.fuse_x != nullptr) {                               // one launch: the kernel quantises the rows itself (w4_fusable() said it may)
+        a.fused = true;
+        a.fz = FqlW4Fused{w.fuse_x, w.fuse_gather, w.fuse_n_src, w.row_weight, w.flags, next_fused_token(), g_fused_spin};
+    }
     const int rc = fql_w4_launch(L, nf, depth, a);
     return rc == 0 ? FQL_OK : (rc == -2 ? FQL_ERR_BAD_SHAPE : FQL_ERR_LAUNCH);
 }
@@ -565,6 +604,11 @@ int run_mfma(int L, const void *x, int in_dtype, const int32_t *gather, int n_sr
         rc = launch_act_quant<2>(x, in_dtype, gather, n_src, w, T, K, Kp, MBT, zero_out, out_dtype, N, tpe, offs, E, st, gated);
         if (rc != FQL_OK) return rc;
         return launch_gemm<2>(cfg, w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, st);
+    }
+    if (g_fused && cfg == 301 && in_dtype == FQL_DTYPE_F32 && !gated && w.flags != nullptr && (K % 16 == 0) && aligned16(x) &&
+        w4_fusable(6, tpe, E, T, N)) {
+        w.fuse_x = x; w.fuse_gather = gather; w.fuse_n_src = n_src;      // no pre-pass launch: the GEMM kernel's first phase
+        return launch_gemm<3>(cfg, w, packed, scales, zps, out, out_dtype, tpe, offs, E, T, K, Kp, MBT, N, st);
     }
     rc = launch_act_quant<3>(x, in_dtype, gather, n_src, w, T, K, Kp, MBT, zero_out, out_dtype, N, tpe, offs, E, st, gated);
     if (rc != FQL_OK) return rc;
@@ -1225,6 +1269,8 @@ FQL_API int fql_tune_chosen_cfg(int precision, int E, int T, int K, int N, int g
     return is_f8(precision) ? choose_cfg_f8(E, T, N, grouped != 0) : choose_cfg(L, E, T, K, N, grouped != 0);
 }
 FQL_API int fql_tune_set_compute_units(int n) { const int old = g_cu_cap; g_cu_cap = n > 0 ? (n < 8 ? 8 : n - n % 8) : 0; return old; }
+FQL_API int fql_tune_set_fused(int on) { const int old = g_fused; g_fused = on ? 1 : 0; return old; }
+FQL_API int fql_tune_set_fused_spin(int polls) { const int old = g_fused_spin; if (polls >= 0) g_fused_spin = polls; return old; }
 FQL_API int fql_tune_set_w4(int on) { const int old = g_use_w4; g_use_w4 = on ? 1 : 0; return old; }
 
 

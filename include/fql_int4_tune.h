@@ -31,6 +31,8 @@ FQL_API int fql_tune_num_w4_configs(void);
 
 /* process-global switches; each returns the previous value */
 FQL_API int fql_tune_set_compute_units(int n);          /* persistent grids sized for n compute units (multiple of 8; 0: the device's); tests use it to walk many tiles per workgroup on small shapes */
+FQL_API int fql_tune_set_fused(int on);                  /* 3 limbs, float32 rows, one-wave-per-SIMD kernel: pre-pass as the GEMM kernel's first phase (ONE launch) */
+FQL_API int fql_tune_set_fused_spin(int polls);          /* polls before a workgroup of that launch quantises the rows it waits for itself (0: at once -- tests) */
 FQL_API int fql_tune_set_w4(int on);                     /* 3 limbs, > 64 rows per group: one-wave-per-SIMD kernel (default on) */
 FQL_API int fql_tune_set_balance_tiles(int on);          /* uneven column tiles that even out the persistent walk (default on) */
 FQL_API int fql_tune_set_gemv_max_rows(int rows);        /* linear op: rows up to which the float32 GEMV kernel runs (default 2) */

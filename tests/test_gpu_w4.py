@@ -226,3 +226,79 @@ def test_visit_sequences_of_mixed_tile_classes(fq, counts, heavy):
             assert not bad, f"configuration {cfg} at {cus} workgroups: rows {bad[:8]} differ from the wide kernel"
     ref = C.moe_grouped(P, S, Z, x, cnt, offs)
     assert rel_fro(ref_out.cpu().numpy(), ref) < EXACT_REL_FRO
+
+
+@pytest.mark.parametrize("counts,heavy,spin,cus", [
+    ([128] * 8, 0, -1, 0),                                  # the headline's routing (at a smaller N / K)
+    ([200, 3, 40, 0, 129, 64, 33, 7, 1, 130], 5, -1, 0),    # every tile class, heavy-tailed rows, an empty expert
+    ([200, 3, 40, 0, 129, 64, 33, 7, 1, 130], 5, 0, 0),     # no polling at all: every workgroup quantises its tiles' rows itself
+    ([60, 150, 20, 140, 10, 50], 7, -1, 64),                # 64 workgroups: several tiles and several row groups per workgroup
+    ([60, 150, 20, 140, 10, 50], 7, 3, 64),                 # ... with a short poll budget (a mix of waiting and self-service)
+])
+def test_one_launch_form_is_bit_identical(fq, counts, heavy, spin, cus):
+    """csrc/fql_gemm_w4.h, FUSED: the pre-pass as the GEMM kernel's first phase (row groups published through flags, each
+    workgroup waits for the rows of its own tiles only and quantises them itself after a bounded number of polls).  Same
+    limbs, same arithmetic: the product call must return the bits of the two-launch form, whatever the polling does."""
+    from fused_int4_amd import ops, _native
+    lib = _native.lib()
+    E, N, K = len(counts), 1500, 1536
+    P, S, Z, x, cnt, offs = make_moe(E, N, K, counts, 11 + sum(counts), heavy_every=heavy)
+    dP, dS, dZ, dx, dc, do = dev(P), dev(S), dev(Z), dev(x), dev(cnt), dev(offs)
+    ref_out = ops.moe_forward(dP, dS, dZ, dx, None, dc, do)
+    torch.cuda.synchronize()
+    old_cus = lib.fql_tune_set_compute_units(cus) if cus else None
+    old_spin = lib.fql_tune_set_fused_spin(spin) if spin >= 0 else None
+    old = lib.fql_tune_set_fused(1)
+    try:
+        outs = [ops.moe_forward(dP, dS, dZ, dx, None, dc, do) for _ in range(3)]     # (fresh tokens: flags of the launch before must not count)
+        torch.cuda.synchronize()
+    finally:
+        lib.fql_tune_set_fused(old)
+        if old_spin is not None:
+            lib.fql_tune_set_fused_spin(old_spin)
+        if old_cus is not None:
+            lib.fql_tune_set_compute_units(old_cus)
+    if cus:                                                   # the reference at the same pretended device (tile widths follow the grid)
+        lib.fql_tune_set_compute_units(cus)
+        try:
+            ref_out = ops.moe_forward(dP, dS, dZ, dx, None, dc, do)
+            torch.cuda.synchronize()
+        finally:
+            lib.fql_tune_set_compute_units(old_cus)
+    for out in outs:
+        bad = (~(out == ref_out).all(dim=1)).nonzero().flatten().tolist()
+        assert not bad, f"rows {bad[:8]} of the one-launch form differ from the two-launch form"
+    ref = C.moe_grouped(P, S, Z, x, cnt, offs)
+    assert rel_fro(ref_out.cpu().numpy(), ref) < EXACT_REL_FRO
+
+
+def test_one_launch_form_linear_and_gather(fq):
+    """The same through the linear entry point (no expert table) and through the fused-dispatch entry point (rows gathered
+    by index, routing weight in the epilogue)."""
+    from fused_int4_amd import ops, _native
+    lib = _native.lib()
+    rng = np.random.default_rng(3)
+    N, K, B = 1100, 1024, 300
+    p, s, z = O.quantize_weights((rng.standard_normal((N, K)) * 0.02).astype(np.float32))
+    x = rng.standard_normal((B, K)).astype(np.float32)
+    x[::13, 5] *= 900.0
+    dp, ds, dz, dx = dev(p), dev(s), dev(z), dev(x)
+    ref_lin = ops.linear_forward(dx, dp, ds, dz)
+    E = 4
+    P, S, Z, xt, cnt, offs = make_moe(E, N, K, [70, 10, 130, 45], 5)
+    tokens = dev(rng.standard_normal((100, K)).astype(np.float32))
+    T = int(cnt.sum())
+    idx = dev(rng.integers(0, 100, size=T).astype(np.int32))
+    rw = dev(rng.random(T).astype(np.float32))
+    dP, dS, dZ, dc, do = dev(P), dev(S), dev(Z), dev(cnt), dev(offs)
+    ref_g = ops.moe_gather_forward(dP, dS, dZ, tokens, idx, dc, do, row_weight=rw)
+    torch.cuda.synchronize()
+    old = lib.fql_tune_set_fused(1)
+    try:
+        got_lin = ops.linear_forward(dx, dp, ds, dz)
+        got_g = ops.moe_gather_forward(dP, dS, dZ, tokens, idx, dc, do, row_weight=rw)
+        torch.cuda.synchronize()
+    finally:
+        lib.fql_tune_set_fused(old)
+    assert torch.equal(got_lin, ref_lin)
+    assert torch.equal(got_g, ref_g)

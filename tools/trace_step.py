@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=2.0)
 ap.add_argument("--counts", default="", help="rows per expert, comma separated (default: 128 each)")
 ap.add_argument("--precision", default="default")
+ap.add_argument("--one-launch", action="store_true", help="the FUSED form: pre-pass as the GEMM kernel's first phase")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 E, K, N = 8, 4096, 11008
@@ -29,6 +30,8 @@ x = torch.randn(T, K, device=dev, generator=g)
 tpe = torch.tensor(counts, dtype=torch.int32, device=dev)
 offs = (torch.cumsum(tpe, 0) - tpe).to(torch.int32)
 lib = _native.lib()
+if a.one_launch:
+    lib.fql_tune_set_fused(1)
 t0 = time.time(); i = 0; n_timed = 0; timing = False
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 while time.time() - t0 < a.seconds:
@@ -52,7 +55,15 @@ def fetch(name, n):
 
 act = fetch("fql_debug_trace_act", 256).reshape(16, 16)
 w4 = fetch("fql_debug_trace_w4", 512).reshape(8, 64)
-t00 = min(int(v) for v in act[:, 0] if v > 0)
+if a.one_launch:
+    act[:] = 0
+    t00 = min(int(w4[b][56]) for b in range(8) if w4[b][56] > 0)
+    print("one launch: GEMM kernel entry | row groups counted | tile table | own rows quantised + published | tiles' rows there | first stage parked")
+    for b in range(8):
+        if w4[b][56] > 0:
+            print(f"  wg {b}: " + " | ".join(f"{(int(w4[b][i]) - t00) / 100.0:6.2f}" for i in (56, 57, 58, 60, 61, 59)))
+else:
+    t00 = min(int(v) for v in act[:, 0] if v > 0)
 us = lambda v: (int(v) - t00) / 100.0 if v > 0 else float("nan")
 print("pre-pass (us after its first workgroup's entry): entry | rows looked up | loads in, row max known | quantised, stores issued | row sums written | exit")
 for s in range(16):
