@@ -404,10 +404,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
             szr[i] = __builtin_bit_cast(float, vs | vz | vb);
         }
     };
+    // (the zero points are parked NEGATED: the epilogue's fmaf(-zp, rowsum, acc) then needs no sign flip per use)
     auto park_sz = [&](float *sz) {
 #pragma unroll
-        for (int i = 0; i < C::SZN; ++i)
-            if (tid + i * C::THREADS < 3 * C::BN) sz[tid + i * C::THREADS] = szr[i];
+        for (int i = 0; i < C::SZN; ++i) {
+            const int idx = tid + i * C::THREADS;
+            if (idx < 3 * C::BN) sz[idx] = (idx >= C::BN && idx < 2 * C::BN) ? -szr[i] : szr[i];
+        }
     };
     // the fragments a visit expects in wf[] when its first k-step starts: the first four of its wave's range, k-step 0 of
     // the stage in `buf` (every slot plan reads its later ones itself).  The plans prefetch the coming step's fragments
@@ -797,13 +800,16 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
 #pragma unroll
         for (int l = 0; l < L; ++l) rs[l] = (float)rsi[l];
         const int nfr_c = cur.nfr - fbase < 0 ? 0 : (cur.nfr - fbase < NACT ? cur.nfr - fbase : NACT);   // this wave's fragments that exist
-        auto out4 = [&](int j, int q, const v4f &s4, const v4f &z4, float (&o)[4]) {
+        // nz4: the NEGATED zero points (park_sz).  tot = ((t_2 * 256 + t_1) * 256 + t_0, t_l = acc_l - zp * rowsum_l: the other
+        // kernels write the first step as fmaf(0, 256, t_2) = t_2 + 0, which differs from t_2 only for t_2 = -0.0 -- and an
+        // fma of a +0.0 / integer-valued addend with an exact-zero result is +0.0 under round-to-nearest: same bits, one add less.
+        auto out4 = [&](int j, int q, const v4f &s4, const v4f &nz4, float (&o)[4]) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float tot = 0.0f;
+                float tot = fmaf(nz4[c], rs[L - 1], (float)acc_val(L - 1, j, 4 * q + c));
 #pragma unroll
-                for (int l = L - 1; l >= 0; --l)
-                    tot = fmaf(tot, 256.0f, fmaf(-z4[c], rs[l], (float)acc_val(l, j, 4 * q + c)));
+                for (int l = L - 2; l >= 0; --l)
+                    tot = fmaf(tot, 256.0f, fmaf(nz4[c], rs[l], (float)acc_val(l, j, 4 * q + c)));
                 o[c] = (tot * d) * s4[c];
             }
         };

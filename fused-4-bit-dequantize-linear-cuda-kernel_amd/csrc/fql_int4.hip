@@ -542,7 +542,9 @@ inline int choose_cfg(int L, int E, int T, int K, int N, bool grouped)
         if (m <= 16) return 207;                             //  16 x 48 decode tiles, K split 8 ways (fql_gemm_rows16.h)
         if (m <= 32) return 8;                               //  32 x 64, 2 waves
         if (m <= 64) return 7;                               //  64 x 64, 4 waves
-        return 13;                                           // 128 x 64, 4 waves, 8 weight stages in flight
+        // 65..128 rows: 128 x 64, 4 waves, 8 weight stages in flight; at 3 limbs the 128 x 128 tile of the wide kernel is
+        // 8-10 % faster (96 rows 38.1 vs 41.3 us, 128 rows 40.3 vs 44.5 us, 4096 -> 11008, profiles/r03_small_groups.txt)
+        return L == 3 ? 1 : 13;
     }
     if (m <= 16) return 202;                                 //  16 x 128 decode tiles: every load one stage ahead
     if (m <= 32) return 103;                                 //  32 x 128, K split 4 ways inside the workgroup
