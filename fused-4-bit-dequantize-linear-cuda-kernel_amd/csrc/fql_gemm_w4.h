@@ -18,13 +18,17 @@
 //     is computed once per workgroup into LDS -- no vector load is ever waited for right after it is issued
 //     (vector-memory operations complete in order: such a wait would drain the whole prefetch queue).
 //
-// LDS image of a weight stage (unpacked; per k-step a plane of BN rows x 2 lane groups x 16 B, planes KSTRIDE apart):
-//   k-step ks, row n of the tile, lane group g  ->  byte ks * KSTRIDE + n * 32 + g * 16,   KSTRIDE = BN * 32 + 16
-// A fragment read (fixed ks, 32 rows x 2 groups) is 1 KiB contiguous: conflict-free, and every read of a stage is
-// ONE per-lane base register + an immediate offset (ks * KSTRIDE + j * 1024) -- the first layout, rows of 256 B with an
-// XOR swizzle of the 16-byte slots, needed 4 vector instructions per k-step to form the address.  The parking
-// ds_write_b128s (32 banks, groups of 8 lanes = the 8 chunks c = 2 v + g' of one row, which go to k-steps 2 v and 2 v + 1,
-// group g') are conflict-free through the 16 bytes added to the plane stride: plane 2 v starts 8 v banks further.
+// LDS image of a weight stage (unpacked; per k-step a plane of NF fragment blocks, planes KSTRIDE apart; a fragment block is
+// the operand of one matrix instruction in LANE ORDER: lane group g, then the fragment's 32 rows, 16 B each):
+//   k-step ks, row n of the tile, lane group g  ->  byte ks * KSTRIDE + (n >> 5) * KFRAG + g * KHALF + (n & 31) * 16
+//   KHALF = 32 * 16 + 16,  KFRAG = 2 * KHALF,  KSTRIDE = NF * KFRAG + 16
+// Every read of a stage is ONE per-lane base register + an immediate offset (ks * KSTRIDE + j * KFRAG) -- the first layout,
+// rows of 256 B with an XOR swizzle of the 16-byte slots, needed 4 vector instructions per k-step to form the address.
+// Banks: a ds_read_b128 is served 16 lanes at a time over 64 banks, and 16 consecutive lanes read 256 contiguous bytes
+// (row-major planes, n * 32 + g * 16, had consecutive lanes 32 B apart: two-way conflicts, SQ_LDS_BANK_CONFLICT 5.7 M of
+// 15 M LDS cycles); the parking ds_write_b128s are served 8 lanes at a time over 32 banks -- the 8 chunks c = 2 v + g' of
+// one row, which go to k-steps 2 v / 2 v + 1, group g': the 16 bytes of padding per lane-group half and per plane put
+// them on 2 v + g' = 8 different 16-byte bank groups.
 //
 // Replaces (reference, CUDA): csrc/moe_int4_kernel.cu:17-136 and csrc/quantized_linear_kernel.cu:90-279.
 #pragma once
@@ -54,7 +58,9 @@ struct W4Cfg {
     static constexpr int BM = 4 * FQL_MB;                    // 128 rows: one 32-row block per wave
     static constexpr int BN = 32 * NF;
     static constexpr int KS = FQL_KB / 32;                   // 8 k-steps per stage
-    static constexpr int KSTRIDE = BN * 32 + 16;             // bytes between the k-step planes of a stage in LDS
+    static constexpr int KHALF = FQL_MB * 16 + 16;           // one lane group of a fragment block: 32 rows x 16 B (+ 16 B: bank spread of the parking stores)
+    static constexpr int KFRAG = 2 * KHALF;                  // one fragment block = one matrix instruction's weight operand
+    static constexpr int KSTRIDE = NF * KFRAG + 16;          // bytes between the k-step planes of a stage in LDS
     static constexpr int W_STAGE = KS * KSTRIDE;             // bytes of UNPACKED weights per stage
     static constexpr int SZ_BYTES = 2 * 3 * BN * 4;          // two scale / zero-point / bias slices
     static constexpr int NTAB = 16;                          // tiles described ahead in LDS
@@ -342,10 +348,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
     const int rowW = wave * 8 + (lane >> 3), chW = lane & 7;
     const int voffW = rowW * (K >> 1) + chW * 16;
     const int pieceW = 32 * (K >> 1);
-    const int wA0 = (chW & ~1) * C::KSTRIDE + rowW * 32 + (chW & 1) * 16;      // k-step 2 v, row, group g'   (+ i * 1024: piece i)
-    const int wA1 = wA0 + C::KSTRIDE;                                          // k-step 2 v + 1
-    // fragment reads: k-step ks, row n = 32 j + l31, group g  ->  ks * KSTRIDE + j * 1024 + (l31 * 32 + g * 16)
-    const int rF0 = l31 * 32 + g * 16;
+    const int wA0 = (chW & ~1) * C::KSTRIDE + (chW & 1) * C::KHALF + rowW * 16;   // k-step 2 v, group g', row   (+ i * KFRAG: piece i)
+    const int wA1 = wA0 + C::KSTRIDE;                                             // k-step 2 v + 1
+    // fragment reads: k-step ks, row n = 32 j + l31, group g  ->  ks * KSTRIDE + j * KFRAG + (g * KHALF + l31 * 16)
+    const int rF0 = g * C::KHALF + l31 * 16;
     float *szbuf = reinterpret_cast<float *>(lds + 2 * C::W_STAGE);
 
     v4i bst[NF];                                             // one packed weight stage in flight (global -> VGPR)
@@ -383,8 +389,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         unpack8((uint32_t)bst[i][1], lo1, hi1);
         unpack8((uint32_t)bst[i][2], lo2, hi2);
         unpack8((uint32_t)bst[i][3], lo3, hi3);
-        *reinterpret_cast<v4i *>(buf + wA0 + i * 1024) = v4i{(int)lo0, (int)hi0, (int)lo1, (int)hi1};
-        *reinterpret_cast<v4i *>(buf + wA1 + i * 1024) = v4i{(int)lo2, (int)hi2, (int)lo3, (int)hi3};
+        *reinterpret_cast<v4i *>(buf + wA0 + i * C::KFRAG) = v4i{(int)lo0, (int)hi0, (int)lo1, (int)hi1};
+        *reinterpret_cast<v4i *>(buf + wA1 + i * C::KFRAG) = v4i{(int)lo2, (int)hi2, (int)lo3, (int)hi3};
     };
     auto issue_sz = [&](const GemmTile &tp) {
         const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void *)(scales + (size_t)tp.e * N), 0, N * 4, 0x00020000);
@@ -416,9 +422,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
     // the stage in `buf` (every slot plan reads its later ones itself).  The plans prefetch the coming step's fragments
     // with the CURRENT tile's fragment range, so at a visit boundary they are read again for the next tile's.
     auto read_first_frags = [&](const char *buf, int fb) {
-        const char *p = buf + fb * 1024 + rF0;
+        const char *p = buf + fb * C::KFRAG + rF0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const v4i *>(p + j * 1024);
+        for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const v4i *>(p + j * C::KFRAG);
     };
 
     // ---- kernel prologue: the state every visit starts from
@@ -595,7 +601,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
             //  and spilled)
             int rFo = rF0;
             asm volatile("" : "+v"(rFo));
-            const char *sbf = sb + fbase * 1024 + rFo, *nbf = nb + fbase * 1024 + rFo;
+            const char *sbf = sb + fbase * C::KFRAG + rFo, *nbf = nb + fbase * C::KFRAG + rFo;
             // what the loads of this stage fetch: weights two stages ahead, activations one stage ahead -- of this tile,
             // or of the next visit once this tile's K range is used up
             const bool w_here = kt + 2 < KT;
@@ -669,15 +675,15 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
                                 ring(tk, l) = __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff0, sAq[0][l] + tk * 1024, 0);
                     }
                 };
-                auto frag = [&](const char *base, int j) { if (!(W4_ABLATE & 4)) wf[j] = *reinterpret_cast<const v4i *>(base + j * 1024); };
+                auto frag = [&](const char *base, int j) { if (!(W4_ABLATE & 4)) wf[j] = *reinterpret_cast<const v4i *>(base + j * C::KFRAG); };
                 auto unpack = [&](int i) {
                     if (!park) return;
                     unpack8((uint32_t)bst[ks % NF][i], up[2 * i], up[2 * i + 1]);
                     asm volatile("" : "+v"(up[2 * i]), "+v"(up[2 * i + 1]));              // pin the unpack to this slot
                 };
                 static_assert(NF == 6 && L == 3 && NVF == 1, "the slot plans below are written for 6 fragments x 3 limbs, the last fragment in VGPRs");
-                auto park0 = [&]() { if (park) *reinterpret_cast<v4i *>(nb + wA0 + ks * 1024) = v4i{(int)up[0], (int)up[1], (int)up[2], (int)up[3]}; };
-                auto park1 = [&]() { if (park) *reinterpret_cast<v4i *>(nb + wA1 + ks * 1024) = v4i{(int)up[4], (int)up[5], (int)up[6], (int)up[7]}; };
+                auto park0 = [&]() { if (park) *reinterpret_cast<v4i *>(nb + wA0 + ks * C::KFRAG) = v4i{(int)up[0], (int)up[1], (int)up[2], (int)up[3]}; };
+                auto park1 = [&]() { if (park) *reinterpret_cast<v4i *>(nb + wA1 + ks * C::KFRAG) = v4i{(int)up[4], (int)up[5], (int)up[6], (int)up[7]}; };
                 auto stage_barrier = [&]() {
                     if (ks == KS - 1) {
                         // every wave has parked the next stage (steps 0..NF-1) and holds the last fragments of this one
