@@ -5,6 +5,7 @@
 
 #include <type_traits>
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef int v16i __attribute__((ext_vector_type(16)));

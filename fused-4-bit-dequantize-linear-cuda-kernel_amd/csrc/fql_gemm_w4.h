@@ -821,13 +821,16 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
         };
         const bool fast = mode == 0 && vec && out_kind == 0 && bias == nullptr && !row_scaled && cur.n0 + (fbase + nfr_c) * 32 <= N &&
                           (size_t)T * (size_t)N < ((size_t)1 << 29);      // (32-bit byte offsets into `out`)
+        // the same for 16-bit outputs (float16 / bfloat16 rows out: one 8-byte store per quad)
+        const bool fast16 = mode == 0 && vec && out_kind != 0 && bias == nullptr && !row_scaled && cur.n0 + (fbase + nfr_c) * 32 <= N &&
+                            (size_t)T * (size_t)N < ((size_t)1 << 29);
         if (row_ok_e && !(W4_ABLATE & 16)) {
             // One fragment (32 columns = 16 outputs of this lane) at a time: all its arithmetic as straight-line code, then
             // ONE branch on how to store -- the common case (float32 outputs, whole 16-byte stores, every column inside N)
             // or the general one.  (Two copies of the arithmetic, one per case, get their accumulator reads hoisted in
             // front of the branch by the compiler -- all 288 registers at once.)
-            const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((size_t)T * N * 4), 0x00020000);
-            const int ovoff = (t_e * N + cur.n0 + fbase * 32 + 4 * g_e) * 4;
+            const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((size_t)T * N * (out_kind == 0 ? 4 : 2)), 0x00020000);
+            const int ovoff = (t_e * N + cur.n0 + fbase * 32 + 4 * g_e) * (out_kind == 0 ? 4 : 2);
             float *slot0 = res_scratch + ((size_t)blockIdx.x * C::NW + wave) * (NF * 1024) + lane_e * 4;
 #pragma unroll
             for (int j = 0; j < NACT; ++j) {
@@ -851,6 +854,15 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
                         __builtin_amdgcn_raw_buffer_store_b128(v4i{__builtin_bit_cast(int, o[q][0]), __builtin_bit_cast(int, o[q][1]),
                                                                    __builtin_bit_cast(int, o[q][2]), __builtin_bit_cast(int, o[q][3])},
                                                                rsO, ovoff, (j * 32 + 8 * q) * 4, 0);
+                } else if (fast16) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        unsigned short h[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) h[c] = (out_kind == 1) ? f32_to_f16_bits(o[q][c]) : f32_to_bf16_bits(o[q][c]);
+                        __builtin_amdgcn_raw_buffer_store_b64(v2i{(int)((uint32_t)h[0] | ((uint32_t)h[1] << 16)), (int)((uint32_t)h[2] | ((uint32_t)h[3] << 16))},
+                                                              rsO, ovoff, (j * 32 + 8 * q) * 2, 0);
+                    }
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
