@@ -819,10 +819,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
                 o[c] = (tot * d) * s4[c];
             }
         };
-        const bool fast = mode == 0 && vec && out_kind == 0 && bias == nullptr && !row_scaled && cur.n0 + (fbase + nfr_c) * 32 <= N &&
+        // (bias and row weight are applied on the way: one LDS read + add, one multiply per quad, wave-uniform branches)
+        const bool fast = mode == 0 && vec && out_kind == 0 && cur.n0 + (fbase + nfr_c) * 32 <= N &&
                           (size_t)T * (size_t)N < ((size_t)1 << 29);      // (32-bit byte offsets into `out`)
         // the same for 16-bit outputs (float16 / bfloat16 rows out: one 8-byte store per quad)
-        const bool fast16 = mode == 0 && vec && out_kind != 0 && bias == nullptr && !row_scaled && cur.n0 + (fbase + nfr_c) * 32 <= N &&
+        const bool fast16 = mode == 0 && vec && out_kind != 0 && cur.n0 + (fbase + nfr_c) * 32 <= N &&
                             (size_t)T * (size_t)N < ((size_t)1 << 29);
         if (row_ok_e && !(W4_ABLATE & 16)) {
             // One fragment (32 columns = 16 outputs of this lane) at a time: all its arithmetic as straight-line code, then
@@ -844,6 +845,22 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(
                     const v4f s4 = *reinterpret_cast<const v4f *>(sz + c0);
                     const v4f z4 = *reinterpret_cast<const v4f *>(sz + C::BN + c0);
                     out4(j, q, s4, z4, o[q]);
+                }
+                if (fast || fast16) {                        // (the same order as the general path below: + bias, then x row weight)
+                    if (bias != nullptr) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const v4f b4 = *reinterpret_cast<const v4f *>(sz + 2 * C::BN + (fbase + j) * 32 + 8 * q + 4 * g_e);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) o[q][c] += b4[c];
+                        }
+                    }
+                    if (row_scaled) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) o[q][c] *= rw;
+                    }
                 }
                 if (fast) {
                     // (buffer stores: ONE 32-bit offset register per lane, fragment and quad in the scalar offset -- 64-bit
