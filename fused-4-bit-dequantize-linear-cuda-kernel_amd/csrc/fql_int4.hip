@@ -180,6 +180,8 @@ constexpr int FQL_NUM_ROWS32 = 8;
     S(7, 3, 8, 1)              /* 16 x  48, one weight stage in flight */ \
     S(8, 2, 8, 2)              /* 16 x  32 */
 constexpr int FQL_NUM_ROWS16 = 9;
+// (round 3: 16 x 192 and 16 x 160 -- two tiles per workgroup at the decode shape instead of three -- were built and timed: 47.1 / 49.4 us
+//  against 46.1 us for id 2, at 253-256 registers; profiles/r03_decode_phase_trace.txt.  Not kept.)
 // the same kernel as 4-wave workgroups, two per CU.  ids 220 + i.  S4(i, NF, KG, weight stages in flight)
 #define FQL_ROWS16_W4_LIST(S4)                                                                                     \
     S4(0, 4, 4, 1)             /* 16 x  64, K split 4 ways */ \
