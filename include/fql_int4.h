@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define FQL_VERSION 200 /* 0.2.0: fp8 activations; residual limb set for heavy-tailed rows (two-phase buffers doubled) */
+#define FQL_VERSION 210 /* 0.2.1: fql_moe_gather_scaled_fwd_f32, fql_combine_f32 with NULL weights; the 3-limb workspace grew by one flag word per 4 rows (size it with fql_*_workspace_bytes, as always).  0.2.0: fp8 activations; residual limb set for heavy-tailed rows (two-phase buffers doubled) */
 
 #if defined(__GNUC__)
 #define FQL_API __attribute__((visibility("default")))
