@@ -450,7 +450,7 @@ def main():
         t_g = extra["ep_phases_ms_max_over_ranks"].get("regroup_and_grouped_gemm")
         if t_g:
             ach = flops / world / (t_g * 1e-3) / 1e12
-            ep_roofline = {"bound": "mfma", "kernel": "gemm_i8_kernel (local experts of one rank)", "achieved": ach,
+            ep_roofline = {"bound": "mfma", "kernel": "grouped INT4 GEMM of one rank's local experts (gemm_w4_kernel / gemm_i8_* by rows per expert)", "achieved": ach,
                            "peak": MFMA_I8_PEAK_TOPS, "unit": "TFLOP/s", "frac": ach / MFMA_I8_PEAK_TOPS, "traffic": None,
                            "note": "per GPU: this rank's share of the algorithmic flops over its regroup + pre-pass + grouped "
                                    "GEMM phase (GPU events, max over ranks); the step itself is all-to-all latency bound"}
